@@ -1,0 +1,142 @@
+/*
+ * subgraph_sketch.h -- C ABI of the MI355X (gfx950) subgraph-sketching engine.
+ *
+ * The reference (melifluos/subgraph-sketching) has no FFI layer: its hot path is the Python class
+ * `ElphHashes` in src/hashing.py.  This header is the boundary a replacement binds to; each entry
+ * point names the reference code it replaces (file:line under /root/reference).  The Python host
+ * class in subgraph-sketching_amd/hashing.py is the only in-tree caller (through ctypes); the
+ * reference-side binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  Every data pointer is a DEVICE pointer unless the
+ *     comment says "host".  No torch types.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and returns 0 on success or a negative SS_ERR_* code (argument / launch errors are detected
+ *     synchronously on the host; nothing is thrown).
+ *   - Canonical sketch layout in HBM ("packed"): MinHash rows are uint32[P] (every reference value
+ *     is < 2^32, hashing.py:59,122), HyperLogLog rows are uint8[M], M = 2^p (values 0..64-p,
+ *     hashing.py:75-76).  Row-major [N, P] / [N, M], rows 16-byte aligned (P % 4 == 0, p >= 4).
+ *   - The caller owns every buffer, including workspaces.
+ */
+#ifndef SUBGRAPH_SKETCH_H
+#define SUBGRAPH_SKETCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_OK 0
+#define SS_ERR_INVALID_ARG (-1)   /* null pointer / size / unsupported P, p, h                    */
+#define SS_ERR_LAUNCH (-2)        /* hipGetLastError() != hipSuccess after a launch                */
+#define SS_ERR_WORKSPACE (-3)     /* workspace too small                                           */
+#define SS_ERR_UNSUPPORTED (-4)   /* parameter combination has no kernel                           */
+
+#define SS_MAX_HOPS 3             /* hashing.py:54 */
+#define SS_MAX_TABLE 512          /* max entries of the HLL++ bias tables (datasketch ships <= 200) */
+
+/* flags of ss_pair_features (hashing.py:56,67) */
+#define SS_FLAG_USE_ZERO_ONE 1u
+#define SS_FLAG_FLOOR_SF 2u
+
+/* HyperLogLog++ estimator constants -- everything ElphHashes.__init__ takes from datasketch
+ * (hashing.py:69-80) plus two host-derived helpers.  All fp32 values are rounded on the host exactly
+ * as torch rounds the reference's Python scalars. */
+typedef struct ss_hll_params {
+    int32_t p;              /* hll_p; m = 1 << p                                   (hashing.py:65-66) */
+    int32_t n_tbl;          /* entries in raw_est / bias, 6 <= n_tbl <= SS_MAX_TABLE                  */
+    float alpha_mm;         /* fp32(alpha * m^2)                                   (hashing.py:228)   */
+    float threshold;        /* fp32(hll_threshold)                                 (hashing.py:78)    */
+    int32_t lc_min_zeros;   /* linear counting is returned iff V >= lc_min_zeros (V = #zero registers,
+                               V > 0); derived on the host from lc_table <= threshold (hashing.py:220-226) */
+    int32_t reserved;
+    const float *raw_est;   /* device [n_tbl]: estimate_vector SORTED ascending     (hashing.py:80)    */
+    const float *bias;      /* device [n_tbl]: bias_vector, permuted like raw_est  (hashing.py:79)    */
+    const float *lc_table;  /* device [m+1]: lc_table[V] = m*log(m/V) in fp32, V>=1 (hashing.py:194-195) */
+} ss_hll_params;
+
+/* library / build identification */
+int ss_version(void);
+const char *ss_error_string(int code);
+
+/* Hop-0 MinHash rows.  Replaces ElphHashes.initialise_minhash (hashing.py:118-124); a/b are the
+ * permutation parameters of _init_permutations (hashing.py:106-116, drawn on the host with numpy's
+ * RandomState(1)), device uint64[P].  Writes rows for nodes first_node .. first_node+n-1
+ * (node id i hashes the value i+1, hashing.py:121). */
+int ss_minhash_init(uint32_t *out, int64_t first_node, int64_t n, const uint64_t *a, const uint64_t *b, int32_t P,
+                    void *stream);
+
+/* Hop-0 HyperLogLog rows.  Replaces ElphHashes.initialise_hll + _get_hll_rank (hashing.py:126-137,
+ * 91-104): one non-zero register per row. */
+int ss_hll_init(uint8_t *out, int64_t first_node, int64_t n, int32_t p, void *stream);
+
+/* CSR-by-destination of an edge list.  Replaces the message materialisation of
+ * torch_geometric MessagePassing.propagate as used by hashing.py:34,44 (flow source -> target).
+ *   src/dst: device int64[E] (edge_index[0], edge_index[1]);  rowptr: device int64[N+1];
+ *   col: device int32[E] (source ids grouped by destination, order inside a row unspecified).
+ *   err_flag: device int32, set to 1 if any endpoint is outside [0, N) (such edges are dropped).
+ * Workspace: ss_csr_workspace_bytes(N, E) bytes. */
+size_t ss_csr_workspace_bytes(int64_t N, int64_t E);
+int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
+                 int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream);
+
+/* One hop of sketch propagation over a CSR: out[i] = min (MinHash) / max (HLL) over the in-neighbours
+ * of i, plus row i itself when i < n_self_loops (the implicit self loops of add_self_loops,
+ * hashing.py:148); rows with no in-edge and no self loop are all-zero (PyG scatter default).
+ * Replaces MinhashPropagation.forward / HllPropagation.forward (hashing.py:28-45) and, when
+ * cards_out != NULL, the hll_count of hashing.py:163 (cards_out[i*cards_stride] = hll_count(out row)).
+ * Either sketch may be NULL (both in and out). */
+int ss_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
+                 const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
+                 const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
+                 float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream);
+
+/* HLL++ cardinality of n register rows.  Replaces ElphHashes.hll_count (+ _linearcounting,
+ * _estimate_bias, _refine_hll_count_estimate; hashing.py:194-232).  regs: device uint8[n, m];
+ * out: device fp32, element i written to out[i*out_stride]. */
+int ss_hll_count(const uint8_t *regs, int64_t n, const ss_hll_params *prm, float *out, int64_t out_stride,
+                 void *stream);
+
+/* The two estimator helpers the reference exposes on their own.  e: device fp32[n] raw estimates.
+ *   refine == 0: out[i] = mean bias of the 6 nearest table entries   (_estimate_bias, hashing.py:197-204)
+ *   refine != 0: out[i] = e[i] <= 5m ? e[i] - that bias : e[i]       (_refine_hll_count_estimate, :206-210) */
+int ss_estimate_bias(const float *e, int64_t n, const ss_hll_params *prm, float *out, int32_t refine, void *stream);
+
+/* Subgraph features of B node pairs.  Replaces ElphHashes._get_intersections + jaccard + _hll_merge +
+ * get_subgraph_features for one chunk (hashing.py:167-189, 234-237, 247-256, 258-323).
+ *   links: device int64[B,2]; negative ids wrap like torch indexing; ids outside [-N, N) set *err_flag
+ *          (device int32, may be NULL) and produce NaN rows.
+ *   mh / hll: HOST arrays of h device pointers, entry k-1 = hop-k table (k = 1..h).
+ *   cards: device fp32, cards[i*cards_stride + k-1] = hop-k cardinality of node i.
+ *   out: device fp32 [B, h(h+2)], feature order = LABEL_LOOKUP[h] (hashing.py:22-25).
+ *   dbg_match / dbg_zero (device int32[B,h*h], nullable): MinHash match counts and union zero-register
+ *   counts per (k1,k2) row-major; dbg_inter (device fp32[B,h*h], nullable): the intersections J*U. */
+int ss_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
+                     const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
+                     const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
+                     float *out, int32_t *dbg_match, int32_t *dbg_zero, float *dbg_inter, int32_t *err_flag,
+                     void *stream);
+
+/* int64 <-> packed uint32 MinHash tables (the reference's tensors are int64, hashing.py:124). */
+int ss_pack_minhash(const int64_t *in, uint32_t *out, int64_t count, void *stream);
+int ss_unpack_minhash(const uint32_t *in, int64_t *out, int64_t count, void *stream);
+
+/* Launch-duration probe for bench.py: records HIP events around `reps` back-to-back launches of the
+ * same ss_propagate / ss_pair_features call ON `stream` and returns the mean milliseconds per launch in
+ * *ms_out (host pointer).  Synchronises the stream. */
+int ss_time_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
+                      const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
+                      const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
+                      float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream,
+                      int32_t reps, float *ms_out);
+int ss_time_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
+                          const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
+                          const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
+                          float *out, void *stream, int32_t reps, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUBGRAPH_SKETCH_H */

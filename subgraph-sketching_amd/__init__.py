@@ -1,0 +1,11 @@
+"""subgraph-sketching_amd -- MI355X (gfx950) engine for the ELPH/BUDDY subgraph-sketching hot path.
+
+Import name: `subgraph_sketching_amd` (see /subgraph_sketching_amd.py; the directory keeps the project's
+hyphenated name).  Public surface = the reference's src/hashing.py surface.
+"""
+from .hashing import (LABEL_LOOKUP, ElphHashes, HllPropagation, HopSketch, MinhashPropagation, SketchTable,
+                      build_csr, pack_minhash, unpack_minhash)
+from . import _native, hll_tables, dist
+
+__all__ = ['LABEL_LOOKUP', 'ElphHashes', 'HllPropagation', 'MinhashPropagation', 'SketchTable', 'HopSketch',
+           'build_csr', 'pack_minhash', 'unpack_minhash', 'hll_tables', 'dist']

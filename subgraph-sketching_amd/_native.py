@@ -1,0 +1,79 @@
+"""ctypes binding of the C-ABI library (include/subgraph_sketch.h).
+
+The HIP library is the product: there is no CPU fallback.  `lib()` raises loudly when the shared
+object has not been built (run `python __graft_entry__.py` or `subgraph-sketching_amd/csrc/build.sh`).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsubgraph_sketch.so')
+
+SS_MAX_HOPS = 3
+SS_MAX_TABLE = 512
+SS_FLAG_USE_ZERO_ONE = 1
+SS_FLAG_FLOOR_SF = 2
+
+
+class HllParams(ctypes.Structure):
+    """mirror of `struct ss_hll_params`"""
+    _fields_ = [('p', c_int32), ('n_tbl', c_int32), ('alpha_mm', c_float), ('threshold', c_float),
+                ('lc_min_zeros', c_int32), ('reserved', c_int32),
+                ('raw_est', c_void_p), ('bias', c_void_p), ('lc_table', c_void_p)]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/subgraph_sketch.h
+SIGNATURES = {
+    'ss_version': (c_int32, []),
+    'ss_error_string': (c_char_p, [c_int32]),
+    'ss_minhash_init': (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]),
+    'ss_hll_init': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    'ss_csr_workspace_bytes': (c_size_t, [c_int64, c_int64]),
+    'ss_csr_build': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                               c_void_p]),
+    'ss_propagate': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                               c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p]),
+    'ss_hll_count': (c_int32, [c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int64, c_void_p]),
+    'ss_estimate_bias': (c_int32, [c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int32, c_void_p]),
+    'ss_pair_features': (c_int32, [c_void_p, c_int64, c_int64, c_int32, POINTER(c_void_p), c_int32, POINTER(c_void_p),
+                                   c_void_p, c_int64, POINTER(HllParams), c_uint32, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
+    'ss_pack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'ss_unpack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'ss_time_propagate': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p,
+                                    c_void_p, c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int32,
+                                    POINTER(c_float)]),
+    'ss_time_pair_features': (c_int32, [c_void_p, c_int64, c_int64, c_int32, POINTER(c_void_p), c_int32,
+                                        POINTER(c_void_p), c_void_p, c_int64, POINTER(HllParams), c_uint32, c_void_p,
+                                        c_void_p, c_int32, POINTER(c_float)]),
+}
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """load (once) and return the ctypes handle; raises NativeLibraryMissing if it was never built"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f'{LIB_PATH} not found: the HIP engine is not built. Run `python __graft_entry__.py` '
+                f'(or subgraph-sketching_amd/csrc/build.sh). There is no CPU fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().ss_error_string(code).decode()
+        raise RuntimeError(f'{what} failed: {msg} ({code})')

@@ -1,0 +1,203 @@
+// ss_common.hpp -- shared device helpers for the gfx950 subgraph-sketching kernels.
+// Wavefront = 64 lanes; a DPP "row" = 16 lanes, which is the unit one node pair / one HLL row
+// segment is mapped to throughout (see DESIGN.md "lane mapping").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "subgraph_sketch.h"
+
+#define SS_LAUNCH_CHECK()                                        \
+    do {                                                         \
+        if (hipGetLastError() != hipSuccess) return SS_ERR_LAUNCH; \
+    } while (0)
+
+namespace ss {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+constexpr int kRow = 16;  // lanes per DPP row
+
+// pandas.util.hash_array on int64 data == splitmix64 finaliser (reference hashing.py:121,128)
+__device__ __forceinline__ uint64_t hash_u64(uint64_t x)
+{
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return x;
+}
+
+// x mod (2^61 - 1) for any 64-bit x
+__device__ __forceinline__ uint64_t mod_mersenne61(uint64_t x)
+{
+    const uint64_t M = (1ULL << 61) - 1;
+    uint64_t r = (x & M) + (x >> 61);
+    return r >= M ? r - M : r;
+}
+
+// ---- byte-parallel helpers on HLL registers (4 registers per dword) --------------------------------
+// even/odd byte split: both halves are valid packed-u16 operands (odd bytes stay in the high byte of
+// each u16 lane, so unsigned 16-bit max orders them like the bytes).
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
+{
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, y));
+}
+__device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
+{
+    const uint32_t e = pk_max_u16(a & 0x00FF00FFu, b & 0x00FF00FFu);
+    const uint32_t o = pk_max_u16(a & 0xFF00FF00u, b & 0xFF00FF00u);
+    return e | o;
+}
+__device__ __forceinline__ u32x4 bytemax16(u32x4 a, u32x4 b)
+{
+    u32x4 r;
+    r.x = bytemax4(a.x, b.x);
+    r.y = bytemax4(a.y, b.y);
+    r.z = bytemax4(a.z, b.z);
+    r.w = bytemax4(a.w, b.w);
+    return r;
+}
+__device__ __forceinline__ u32x4 min4(u32x4 a, u32x4 b)
+{
+    u32x4 r;
+    r.x = a.x < b.x ? a.x : b.x;
+    r.y = a.y < b.y ? a.y : b.y;
+    r.z = a.z < b.z ? a.z : b.z;
+    r.w = a.w < b.w ? a.w : b.w;
+    return r;
+}
+
+// 2^-r as fp32 for r in 0..126, built from the exponent field (exact)
+__device__ __forceinline__ float exp2_neg(uint32_t r) { return __uint_as_float((127u - r) << 23); }
+
+// zero-register count and harmonic sum of the 4 registers of one dword
+__device__ __forceinline__ void hll_dword_stats(uint32_t w, int &zeros, float &sum)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t r = (w >> (8 * k)) & 0xFFu;
+        zeros += (r == 0u);
+        sum += exp2_neg(r);
+    }
+}
+
+// ---- DPP reductions inside a 16-lane row: every lane ends with the row total ----------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // row_half_mirror: i <-> 7-i inside each 8 lanes
+constexpr int kDppMirror = 0x140;     // row_mirror: i <-> 15-i inside the row
+
+__device__ __forceinline__ int row16_sum_i(int v)
+{
+    v += dpp_i<kDppXor1>(v);
+    v += dpp_i<kDppXor2>(v);
+    v += dpp_i<kDppHalfMirror>(v);
+    v += dpp_i<kDppMirror>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_sum_f(float v)
+{
+    v += __int_as_float(dpp_i<kDppXor1>(__float_as_int(v)));
+    v += __int_as_float(dpp_i<kDppXor2>(__float_as_int(v)));
+    v += __int_as_float(dpp_i<kDppHalfMirror>(__float_as_int(v)));
+    v += __int_as_float(dpp_i<kDppMirror>(__float_as_int(v)));
+    return v;
+}
+
+// ---- HLL++ estimator (reference hashing.py:194-232) ------------------------------------------------
+// Tables are staged by the caller: raw/bias (sorted ascending by raw) and lc (linear-counting values)
+// may point to LDS or global memory.
+struct EstimatorTables {
+    const float *raw;
+    const float *bias;
+    const float *lc;
+    int n_tbl;
+    int lc_min_zeros;
+    float alpha_mm;
+    float five_m;
+};
+
+__device__ __forceinline__ float sqdist(float e, float r)
+{
+    const float d = e - r;
+    return d * d;
+}
+
+// mean of the bias entries at the 6 nearest raw estimates (fp32 squared distance, ties -> lower index):
+// hashing.py:197-204.  raw is sorted, so the answer is a window of 6 consecutive entries.
+__device__ __forceinline__ float bias_of_6nn(const EstimatorTables &t, float e)
+{
+    int lo = 0, hi = t.n_tbl;  // lower_bound: first index with raw >= e
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (t.raw[mid] < e) lo = mid + 1; else hi = mid;
+    }
+    int w = lo - 3;
+    w = w < 0 ? 0 : w;
+    w = w > t.n_tbl - 6 ? t.n_tbl - 6 : w;
+    while (w + 6 < t.n_tbl && sqdist(e, t.raw[w + 6]) < sqdist(e, t.raw[w])) ++w;
+    while (w > 0 && sqdist(e, t.raw[w - 1]) <= sqdist(e, t.raw[w + 5])) --w;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += t.bias[w + k];
+    return s / 6.0f;
+}
+
+// zeros = number of zero registers, hsum = sum_j 2^-reg_j
+__device__ __forceinline__ float hll_estimate(const EstimatorTables &t, int zeros, float hsum)
+{
+    if (zeros > 0 && zeros >= t.lc_min_zeros) return t.lc[zeros];  // linear counting (:221-226)
+    float e = t.alpha_mm / hsum;                                    // raw estimate    (:228)
+    if (e <= t.five_m) e -= bias_of_6nn(t, e);                      // bias correction (:206-210)
+    return e;
+}
+
+// cooperative staging of the estimator tables into LDS (all threads of the block call this)
+constexpr int kLcLdsMax = 1025;  // lc table staged in LDS when m + 1 <= kLcLdsMax (p <= 10)
+struct EstimatorLds {
+    float raw[SS_MAX_TABLE];
+    float bias[SS_MAX_TABLE];
+    float lc[kLcLdsMax];
+};
+
+__device__ __forceinline__ EstimatorTables stage_tables(EstimatorLds &lds, const ss_hll_params &prm)
+{
+    const int m1 = (1 << prm.p) + 1;
+    for (int i = threadIdx.x; i < prm.n_tbl; i += blockDim.x) {
+        lds.raw[i] = prm.raw_est[i];
+        lds.bias[i] = prm.bias[i];
+    }
+    const bool lc_in_lds = m1 <= kLcLdsMax;
+    if (lc_in_lds)
+        for (int i = threadIdx.x; i < m1; i += blockDim.x) lds.lc[i] = prm.lc_table[i];
+    __syncthreads();
+    EstimatorTables t;
+    t.raw = lds.raw;
+    t.bias = lds.bias;
+    t.lc = lc_in_lds ? lds.lc : prm.lc_table;
+    t.n_tbl = prm.n_tbl;
+    t.lc_min_zeros = prm.lc_min_zeros;
+    t.alpha_mm = prm.alpha_mm;
+    t.five_m = 5.0f * (float)(1 << prm.p);
+    return t;
+}
+
+inline int check_params(const ss_hll_params *prm)
+{
+    if (!prm) return SS_ERR_INVALID_ARG;
+    if (prm->p < 4 || prm->p > 16) return SS_ERR_UNSUPPORTED;
+    if (prm->n_tbl < 6 || prm->n_tbl > SS_MAX_TABLE) return SS_ERR_INVALID_ARG;
+    if (!prm->raw_est || !prm->bias || !prm->lc_table) return SS_ERR_INVALID_ARG;
+    return SS_OK;
+}
+
+}  // namespace ss

@@ -1,0 +1,262 @@
+// ss_pairs.hip -- per-node-pair subgraph features (the query side of the hot path).
+//
+// Replaces ElphHashes._get_intersections / jaccard / _hll_merge / hll_count / get_subgraph_features
+// for one chunk of pairs (reference hashing.py:167-189, 234-237, 247-256, 258-323).
+//
+// HBM-bound gather: a pair (u, v) touches 2h sketch rows of 4P + M bytes (768 B at P=128, p=8) exactly
+// once -- the reference gathers every row h times per call (hashing.py:180-183).
+//
+// Mapping: one 16-lane DPP row per pair, 4 pairs per wavefront, 16 per 256-thread block.  Lane l of a
+// row owns 16-byte chunks l, l+16, ... of each sketch row (P=128, M=256: two MinHash chunks and one HLL
+// chunk per row, all dwordx4 loads, 2h rows in flight per pair = 12 KiB per wave at h=2).  Per (k1,k2):
+// MinHash equality count, byte-wise HLL union max, zero-register count and harmonic sum are reduced
+// inside the row with DPP (quad_perm / row_half_mirror / row_mirror -- no LDS traffic), then lane c < h^2
+// runs the HLL++ estimator for combination c and the h(h+2) features are assembled in fp32 in the
+// reference's own operation order.
+#include "ss_common.hpp"
+
+namespace ss {
+
+struct PairTables {
+    const uint32_t *mh[SS_MAX_HOPS];
+    const uint8_t *hll[SS_MAX_HOPS];
+};
+
+__device__ __forceinline__ int eq4(u32x4 a, u32x4 b)
+{
+    return (int)(a.x == b.x) + (int)(a.y == b.y) + (int)(a.z == b.z) + (int)(a.w == b.w);
+}
+
+__device__ __forceinline__ void union_stats(u32x4 a, u32x4 b, int &zeros, float &hsum)
+{
+    const u32x4 m = bytemax16(a, b);
+    hll_dword_stats(m.x, zeros, hsum);
+    hll_dword_stats(m.y, zeros, hsum);
+    hll_dword_stats(m.z, zeros, hsum);
+    hll_dword_stats(m.w, zeros, hsum);
+}
+
+// feature algebra of get_subgraph_features (hashing.py:276-320); I is indexed [k1-1][k2-1].
+template <int H>
+__device__ __forceinline__ void assemble_features(const float (&I)[H][H], const float (&c1)[H], const float (&c2)[H],
+                                                  uint32_t flags, float (&f)[H * (H + 2)])
+{
+    f[0] = I[0][0];
+    if constexpr (H == 1) {
+        f[1] = c2[0] - f[0];
+        f[2] = c1[0] - f[0];
+    } else if constexpr (H == 2) {
+        f[1] = I[1][0] - f[0];
+        f[2] = I[0][1] - f[0];
+        f[3] = I[1][1] - f[0] - f[1] - f[2];
+        f[4] = c2[0] - (f[0] + f[1]);
+        f[5] = c1[0] - f[0] - f[2];
+        f[6] = c2[1] - ((((f[0] + f[4]) + f[1]) + f[2]) + f[3]);  /* torch.sum order over 5 strided floats, see note */
+        f[7] = c1[1] - f[0] - (((f[0] + f[1]) + f[2]) + f[3]) - f[5];  // f0 twice, as the reference (:287)
+    } else {
+        f[1] = I[1][0] - f[0];
+        f[2] = I[0][1] - f[0];
+        f[3] = I[1][1] - f[0] - f[1] - f[2];
+        f[4] = I[2][0] - f[0] - f[1];
+        f[5] = I[0][2] - f[0] - f[2];
+        const float s04 = ((f[0] + f[1]) + f[2]) + f[3];
+        f[6] = I[2][1] - s04 - f[4];
+        f[7] = I[1][2] - s04 - f[5];
+        f[8] = I[2][2] - (((((((f[0] + f[1]) + f[2]) + f[3]) + f[4]) + f[5]) + f[6]) + f[7]);
+        f[9] = c2[0] - f[0] - f[1] - f[4];
+        f[10] = c1[0] - f[0] - f[2] - f[5];
+        const float s05 = (((f[0] + f[4]) + f[1]) + f[2]) + f[3];
+        f[11] = c2[1] - s05 - f[6] - f[9];
+        f[12] = c1[1] - s05 - f[7] - f[10];
+        const float s09 = (((((((f[8] + f[0]) + f[1]) + f[2]) + f[3]) + f[4]) + f[5]) + f[6]) + f[7];
+        f[13] = c2[2] - s09 - f[9] - f[11];
+        f[14] = c1[2] - s09 - f[10] - f[12];
+    }
+    if (!(flags & SS_FLAG_USE_ZERO_ONE)) {
+        if constexpr (H == 2) { f[4] = 0.0f; f[5] = 0.0f; }
+        if constexpr (H == 3) { f[4] = 0.0f; f[5] = 0.0f; f[11] = 0.0f; f[12] = 0.0f; }
+    }
+    if (flags & SS_FLAG_FLOOR_SF) {
+#pragma unroll
+        for (int k = 0; k < H * (H + 2); ++k) f[k] = f[k] < 0.0f ? 0.0f : f[k];
+    }
+}
+
+// TP, TM > 0: compile-time sketch sizes, all 2H rows register-resident (fast path).
+// TP = TM = 0: run-time sizes, rows re-read per (k1,k2) (parameter sweeps / tests; not tuned).
+template <int H, int TP, int TM>
+__global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__restrict__ links, int64_t B, int64_t N, PairTables tabs,
+                                                            int P_rt, int M_rt, const float *__restrict__ cards, int64_t cards_stride,
+                                                            ss_hll_params prm, uint32_t flags, float *__restrict__ out,
+                                                            int32_t *__restrict__ dbg_match, int32_t *__restrict__ dbg_zero,
+                                                            float *__restrict__ dbg_inter, int32_t *__restrict__ err)
+{
+    __shared__ EstimatorLds lds;
+    const EstimatorTables est = stage_tables(lds, prm);
+
+    constexpr int NF = H * (H + 2);
+    constexpr int NC = H * H;
+    const int P = TP ? TP : P_rt;
+    const int M = TM ? TM : M_rt;
+    const int l = threadIdx.x & (kRow - 1);
+    const int64_t q_raw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kRow;
+    const bool q_ok = q_raw < B;
+    const int64_t q = q_ok ? q_raw : B - 1;
+
+    int64_t u = links[2 * q], v = links[2 * q + 1];
+    u = u < 0 ? u + N : u;  // torch-style negative indexing
+    v = v < 0 ? v + N : v;
+    const bool bad = (uint64_t)u >= (uint64_t)N || (uint64_t)v >= (uint64_t)N;
+    if (bad) { u = 0; v = 0; }
+
+    int mz[NC];     // (match << 20) | zeros, row total
+    float hs[NC];   // harmonic sum, row total
+
+    if constexpr (TP > 0) {
+        constexpr int CMPL = TP / 4 / kRow;   // MinHash chunks per lane
+        constexpr int CHPL = TM / 16 / kRow;  // HLL chunks per lane
+        static_assert(CMPL >= 1 && CHPL >= 1 && (TP / 4) % kRow == 0 && (TM / 16) % kRow == 0, "fast path shape");
+        u32x4 mu[H][CMPL], mv[H][CMPL], hu[H][CHPL], hv[H][CHPL];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+#pragma unroll
+            for (int c = 0; c < CMPL; ++c) {
+                mu[k][c] = *reinterpret_cast<const u32x4 *>(tabs.mh[k] + u * TP + 4 * (l + kRow * c));
+                mv[k][c] = *reinterpret_cast<const u32x4 *>(tabs.mh[k] + v * TP + 4 * (l + kRow * c));
+            }
+#pragma unroll
+            for (int c = 0; c < CHPL; ++c) {
+                hu[k][c] = *reinterpret_cast<const u32x4 *>(tabs.hll[k] + u * TM + 16 * (l + kRow * c));
+                hv[k][c] = *reinterpret_cast<const u32x4 *>(tabs.hll[k] + v * TM + 16 * (l + kRow * c));
+            }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < H; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < H; ++k2) {
+                int match = 0, zeros = 0;
+                float hsum = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CMPL; ++c) match += eq4(mu[k1][c], mv[k2][c]);
+#pragma unroll
+                for (int c = 0; c < CHPL; ++c) union_stats(hu[k1][c], hv[k2][c], zeros, hsum);
+                mz[k1 * H + k2] = row16_sum_i((match << 20) | zeros);
+                hs[k1 * H + k2] = row16_sum_f(hsum);
+            }
+    } else {
+        const int CM = P >> 2, CH = M >> 4;
+#pragma unroll
+        for (int k1 = 0; k1 < H; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < H; ++k2) {
+                int match = 0, zeros = 0;
+                float hsum = 0.0f;
+                for (int c = l; c < CM; c += kRow)
+                    match += eq4(*reinterpret_cast<const u32x4 *>(tabs.mh[k1] + u * P + 4 * c),
+                                 *reinterpret_cast<const u32x4 *>(tabs.mh[k2] + v * P + 4 * c));
+                for (int c = l; c < CH; c += kRow)
+                    union_stats(*reinterpret_cast<const u32x4 *>(tabs.hll[k1] + u * M + 16 * c),
+                                *reinterpret_cast<const u32x4 *>(tabs.hll[k2] + v * M + 16 * c), zeros, hsum);
+                mz[k1 * H + k2] = row16_sum_i((match << 20) | zeros);
+                hs[k1 * H + k2] = row16_sum_f(hsum);
+            }
+    }
+
+    // lane c < H^2 finishes combination c: I = (match / P) * hll_count(union)   (hashing.py:184-187)
+    int my_mz = mz[0];
+    float my_hs = hs[0];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) {
+        my_mz = (l == c) ? mz[c] : my_mz;
+        my_hs = (l == c) ? hs[c] : my_hs;
+    }
+    float my_I = 0.0f;
+    const int my_match = my_mz >> 20, my_zeros = my_mz & 0xFFFFF;
+    if (l < NC) {
+        const float jac = (float)my_match / (float)P;
+        my_I = jac * hll_estimate(est, my_zeros, my_hs);
+    }
+    const int row_base = (threadIdx.x & (kWave - 1)) & ~(kRow - 1);
+    float I[H][H];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) I[c / H][c % H] = __shfl(my_I, row_base + c);
+
+    float c1[H], c2[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        c1[k] = cards[u * cards_stride + k];
+        c2[k] = cards[v * cards_stride + k];
+    }
+    float f[NF];
+    assemble_features<H>(I, c1, c2, flags, f);
+
+    float my_f = f[0];
+#pragma unroll
+    for (int k = 1; k < NF; ++k) my_f = (l == k) ? f[k] : my_f;
+    if (bad) my_f = __uint_as_float(0x7FC00000u);
+    if (q_ok) {
+        if (l < NF) out[q * NF + l] = my_f;
+        if (l < NC) {
+            if (dbg_match) dbg_match[q * NC + l] = my_match;
+            if (dbg_zero) dbg_zero[q * NC + l] = my_zeros;
+            if (dbg_inter) dbg_inter[q * NC + l] = my_I;
+        }
+        if (bad && l == 0 && err) *err = 1;
+    }
+}
+
+template <int H, int TP, int TM>
+int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &tabs, int P, int M, const float *cards,
+                 int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *dbg_match,
+                 int32_t *dbg_zero, float *dbg_inter, int32_t *err, hipStream_t stream)
+{
+    const int pairs_per_block = 256 / kRow;
+    const int64_t blocks = (B + pairs_per_block - 1) / pairs_per_block;
+    hipLaunchKernelGGL((pair_features_kernel<H, TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, links, B, N, tabs, P, M,
+                       cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+template <int H>
+int dispatch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &tabs, int P, int M, const float *cards,
+                   int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *dbg_match,
+                   int32_t *dbg_zero, float *dbg_inter, int32_t *err, hipStream_t stream)
+{
+    if (P == 128 && M == 256)
+        return launch_pairs<H, 128, 256>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero,
+                                         dbg_inter, err, stream);
+    return launch_pairs<H, 0, 0>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter,
+                                 err, stream);
+}
+
+}  // namespace ss
+
+extern "C" int ss_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
+                                const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
+                                const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
+                                float *out, int32_t *dbg_match, int32_t *dbg_zero, float *dbg_inter, int32_t *err_flag,
+                                void *stream)
+{
+    using namespace ss;
+    if (h < 1 || h > SS_MAX_HOPS) return SS_ERR_UNSUPPORTED;  // hashing.py:54, 308-309
+    if (B < 0 || N <= 0) return B == 0 && N >= 0 ? SS_OK : SS_ERR_INVALID_ARG;
+    const int rc = check_params(prm);
+    if (rc != SS_OK) return rc;
+    if (B == 0) return SS_OK;
+    if (!links || !mh || !hll || !cards || !out || cards_stride < h) return SS_ERR_INVALID_ARG;
+    if (P <= 0 || (P & 3) || P > 2048) return SS_ERR_INVALID_ARG;
+    PairTables tabs = {};
+    for (int k = 0; k < h; ++k) {
+        if (!mh[k] || !hll[k]) return SS_ERR_INVALID_ARG;
+        tabs.mh[k] = mh[k];
+        tabs.hll[k] = hll[k];
+    }
+    const int M = 1 << prm->p;
+    hipStream_t s = (hipStream_t)stream;
+    switch (h) {
+        case 1: return dispatch_pairs<1>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, s);
+        case 2: return dispatch_pairs<2>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, s);
+        default: return dispatch_pairs<3>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, s);
+    }
+}

@@ -1,0 +1,588 @@
+"""MI355X-native subgraph sketching behind the reference's `ElphHashes` API.
+
+Host-side mirror of /root/reference/src/hashing.py: same class / method / attribute names, argument
+meaning and error behaviour, so `from src.hashing import ElphHashes, LABEL_LOOKUP` can be pointed at
+this module unchanged.  All sketch arithmetic runs in the hand-written HIP kernels
+of csrc/ through the C ABI of include/subgraph_sketch.h -- there is no CPU fallback: without a HIP
+device or without the built library every compute entry point raises.
+
+Data layout: the engine keeps sketches "packed" in HBM -- MinHash uint32[N, P] (stored in torch.int32
+tensors), HyperLogLog uint8[N, M].  `build_hash_tables` returns a `SketchTable`, a dict
+{hop: {'hll': int8[N, M], 'minhash': int64[N, P]}} exactly like the reference's, whose int64 MinHash
+leaves are only materialised if somebody reads them (torch.save does); the kernels use the packed twin.
+"""
+import logging
+import weakref
+from ctypes import byref, c_float, c_void_p
+
+import numpy as np
+import torch
+
+from . import _native, hll_tables
+
+logger = logging.getLogger(__name__)
+logger.setLevel(logging.INFO)
+
+# reference hashing.py:22-25 -- primary key = max hops, secondary key = feature index, value = (hops from u, hops from v)
+LABEL_LOOKUP = {1: {0: (1, 1), 1: (0, 1), 2: (1, 0)},
+                2: {0: (1, 1), 1: (2, 1), 2: (1, 2), 3: (2, 2), 4: (0, 1), 5: (1, 0), 6: (0, 2), 7: (2, 0)},
+                3: {0: (1, 1), 1: (2, 1), 2: (1, 2), 3: (2, 2), 4: (3, 1), 5: (1, 3), 6: (3, 2), 7: (2, 3), 8: (3, 3),
+                    9: (0, 1), 10: (1, 0), 11: (0, 2), 12: (2, 0), 13: (0, 3), 14: (3, 0)}}
+
+
+# ------------------------------------------------------------------------------------------------
+# device plumbing
+# ------------------------------------------------------------------------------------------------
+def _compute_device(*tensors):
+    """the HIP device the kernels run on: the device of the first GPU tensor, else the current one"""
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError('subgraph-sketching_amd needs a HIP device (MI355X): torch.cuda.is_available() is False '
+                           'and there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _stream(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _check_sizes(num_perm, p):
+    if num_perm <= 0 or num_perm % 4 or num_perm > 2048:
+        raise NotImplementedError(f'minhash_num_perm must be a multiple of 4 in [4, 2048], got {num_perm}')
+    if not 4 <= p <= 16:
+        raise NotImplementedError(f'hll_p must be in [4, 16], got {p}')
+
+
+class _DeviceParams(object):
+    """HLL++ estimator constants resident on one device (struct ss_hll_params + the tensors it points to)"""
+
+    def __init__(self, tables, device):
+        p = tables.p
+        m = 1 << p
+        raw32 = tables.raw_estimate.astype(np.float32)
+        order = np.argsort(raw32, kind='stable')
+        if not 6 <= len(raw32) <= _native.SS_MAX_TABLE:
+            raise ValueError(f'HLL++ bias table must have 6..{_native.SS_MAX_TABLE} entries, got {len(raw32)}')
+        self.raw = torch.from_numpy(raw32[order].copy()).to(device)
+        self.bias = torch.from_numpy(tables.bias.astype(np.float32)[order].copy()).to(device)
+        lc_host = linear_counting_table(m)
+        thr32 = np.float32(tables.threshold)
+        ok = lc_host[1:].numpy() <= thr32
+        if not ok.any() or not np.all(ok[np.argmax(ok):]):
+            raise ValueError('linear-counting table is not monotone against the threshold')
+        self.lc = lc_host.to(device)
+        self.struct = _native.HllParams(p=p, n_tbl=len(raw32), alpha_mm=float(np.float32(tables.alpha * m ** 2)),
+                                        threshold=float(thr32), lc_min_zeros=int(np.argmax(ok)) + 1, reserved=0,
+                                        raw_est=self.raw.data_ptr(), bias=self.bias.data_ptr(),
+                                        lc_table=self.lc.data_ptr())
+
+
+def linear_counting_table(m):
+    """lc[V] = m * log(m / V) for V = 0..m, evaluated by torch on the host in fp32 exactly like the
+    reference's `_linearcounting` (hashing.py:194-195) does for an int64 zero count; entry 0 is unused"""
+    num_zero = torch.arange(0, m + 1, dtype=torch.int64)
+    lc = m * torch.log(m / num_zero)
+    lc[0] = float('inf')
+    return lc.to(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# sketch containers
+# ------------------------------------------------------------------------------------------------
+class HopSketch(dict):
+    """{'hll': int8[N, M], 'minhash': int64[N, P]} of one hop, backed by the packed device tables.
+
+    `mh_u32` (torch.int32 holding uint32 bit patterns) and `hll_u8` are what the kernels read.  The
+    reference-shaped leaves are created on first access, on `home` (the device the reference would have
+    left them on: where edge_index lived)."""
+    _KEYS = ('hll', 'minhash')
+
+    def __init__(self, mh_u32, hll_u8, home):
+        super().__init__({'hll': None, 'minhash': None})
+        self.mh_u32 = mh_u32
+        self.hll_u8 = hll_u8
+        self.home = home
+
+    def _materialise(self, key):
+        val = dict.__getitem__(self, key)
+        if val is None:
+            if key == 'hll':
+                val = self.hll_u8.view(torch.int8)
+            else:
+                val = unpack_minhash(self.mh_u32)
+            if val.device != self.home:
+                val = val.to(self.home)
+            dict.__setitem__(self, key, val)
+        return val
+
+    def __getitem__(self, key):
+        return self._materialise(key) if key in self._KEYS else dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def __reduce__(self):  # pickles (torch.save) as the reference's plain dict of tensors
+        return (dict, (dict(self.items()),))
+
+
+class SketchTable(dict):
+    """{hop: HopSketch}; pickles as a plain dict of dicts (reference datasets/elph.py:204 torch.saves it)"""
+
+    def __reduce__(self):
+        return (dict, ({k: dict(v.items()) if isinstance(v, HopSketch) else v for k, v in self.items()},))
+
+
+def pack_minhash(x, device=None):
+    """int64 [.., P] (values < 2^32, reference hashing.py:124) -> packed uint32 bit patterns in torch.int32"""
+    device = device or _compute_device(x)
+    x = x.to(device=device, dtype=torch.int64).contiguous()
+    out = torch.empty(x.shape, dtype=torch.int32, device=device)
+    _native.check(_native.lib().ss_pack_minhash(_ptr(x), _ptr(out), x.numel(), _stream(device)), 'ss_pack_minhash')
+    return out
+
+
+def unpack_minhash(x_u32):
+    out = torch.empty(x_u32.shape, dtype=torch.int64, device=x_u32.device)
+    _native.check(_native.lib().ss_unpack_minhash(_ptr(x_u32), _ptr(out), x_u32.numel(), _stream(x_u32.device)),
+                  'ss_unpack_minhash')
+    return out
+
+
+def _packed_minhash_of(t, device):
+    """packed twin of a reference-shaped int64 MinHash tensor (cached on the tensor object)"""
+    tw = getattr(t, '_ss_u32', None)
+    if tw is not None and tw.device == device and tw.shape == t.shape:
+        return tw
+    if t.dtype == torch.int32:
+        tw = t.to(device).contiguous()
+    else:
+        tw = pack_minhash(t, device)
+    try:
+        t._ss_u32 = tw
+    except Exception:  # pragma: no cover
+        pass
+    return tw
+
+
+def _packed_hll_of(t, device):
+    tw = getattr(t, '_ss_u8', None)
+    if tw is not None and tw.device == device and tw.shape == t.shape:
+        return tw
+    if t.dtype in (torch.int8, torch.uint8):
+        tw = t.to(device).contiguous().view(torch.uint8)
+    else:
+        tw = t.to(device=device, dtype=torch.uint8).contiguous()
+    try:
+        t._ss_u8 = tw
+    except Exception:  # pragma: no cover
+        pass
+    return tw
+
+
+# ------------------------------------------------------------------------------------------------
+# CSR cache
+# ------------------------------------------------------------------------------------------------
+class CsrGraph(object):
+    """destination-grouped adjacency resident on the device"""
+
+    def __init__(self, rowptr, col, num_nodes, n_self_loops):
+        self.rowptr, self.col, self.num_nodes, self.n_self_loops = rowptr, col, num_nodes, n_self_loops
+
+
+def build_csr(edge_index, num_nodes, device, check=True):
+    """CSR-by-destination of edge_index [2, E] (flow source -> target, reference hashing.py:34,44)"""
+    lib = _native.lib()
+    ei = edge_index.to(device=device, dtype=torch.int64)
+    if ei.dim() != 2 or ei.size(0) != 2:
+        raise ValueError('edge_index must have shape [2, num_edges]')
+    src, dst = ei[0].contiguous(), ei[1].contiguous()
+    E = src.numel()
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=device)
+    col = torch.empty(max(E, 1), dtype=torch.int32, device=device)
+    err = torch.zeros(1, dtype=torch.int32, device=device)
+    ws_bytes = lib.ss_csr_workspace_bytes(num_nodes, E)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+    _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(err), _ptr(ws),
+                                   ws_bytes, _stream(device)), 'ss_csr_build')
+    if check and int(err.item()):
+        raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
+    return CsrGraph(rowptr, col, num_nodes, 0)
+
+
+class _CsrCache(object):
+    """one-entry cache keyed on the identity + version of the edge_index tensor object.  ELPH.forward
+    (reference models/elph.py:209-212) calls hll_prop and minhash_prop h times each with the SAME
+    self-looped edge_index object; this builds its CSR once per forward.  A dead weak reference or a
+    bumped `_version` (in-place edit) invalidates the entry, so recycled allocations are never trusted."""
+
+    def __init__(self):
+        self._ref, self._version, self._key, self._csr = None, None, None, None
+
+    def get(self, edge_index, num_nodes, device):
+        key = (num_nodes, tuple(edge_index.shape), str(device))
+        if self._ref is not None and self._ref() is edge_index and self._version == edge_index._version and self._key == key:
+            return self._csr
+        csr = build_csr(edge_index, num_nodes, device)
+        self._ref, self._version, self._key, self._csr = weakref.ref(edge_index), edge_index._version, key, csr
+        return csr
+
+
+_default_csr_cache = _CsrCache()
+
+
+def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, params=None):
+    """one hop; returns (mh_out or None, hll_out or None).  mh_in packed int32 [N,P], hll_in uint8 [N,M]"""
+    N = csr.num_nodes
+    mh_out = torch.empty_like(mh_in) if mh_in is not None else None
+    hll_out = torch.empty_like(hll_in) if hll_in is not None else None
+    P = mh_in.size(1) if mh_in is not None else 0
+    M = hll_in.size(1) if hll_in is not None else 0
+    prm = byref(params.struct) if params is not None else None
+    _native.check(_native.lib().ss_propagate(_ptr(csr.rowptr), _ptr(csr.col), N, csr.n_self_loops, _ptr(mh_in), _ptr(mh_out),
+                                             P, _ptr(hll_in), _ptr(hll_out), M, _ptr(cards_out), cards_stride, prm,
+                                             _stream(device)), 'ss_propagate')
+    return mh_out, hll_out
+
+
+class MinhashPropagation(object):
+    """drop-in for reference hashing.py:28-35: out[i] = min over in-neighbours (edges j -> i) of x[j];
+    rows without an in-edge are 0.  x: int64 [N, P] with values in [0, 2^32)."""
+
+    def __init__(self, csr_cache=None):
+        self._cache = csr_cache or _default_csr_cache
+
+    @torch.no_grad()
+    def forward(self, x, edge_index):
+        _check_sizes(x.size(1), 8)
+        device = _compute_device(x, edge_index)
+        csr = self._cache.get(edge_index, x.size(0), device)
+        out_u32, _ = _propagate(csr, _packed_minhash_of(x, device), None, device)
+        out = unpack_minhash(out_u32)
+        out._ss_u32 = out_u32
+        return out if x.device == device else out.to(x.device)
+
+    __call__ = forward
+
+
+class HllPropagation(object):
+    """drop-in for reference hashing.py:38-45: out[i] = element-wise max over in-neighbours of x[j]"""
+
+    def __init__(self, csr_cache=None):
+        self._cache = csr_cache or _default_csr_cache
+
+    @torch.no_grad()
+    def forward(self, x, edge_index):
+        M = x.size(1)
+        if M < 16 or M & (M - 1) or M > 65536:
+            raise NotImplementedError(f'HLL rows must have 2^p registers, 4 <= p <= 16, got {M}')
+        device = _compute_device(x, edge_index)
+        csr = self._cache.get(edge_index, x.size(0), device)
+        _, out_u8 = _propagate(csr, None, _packed_hll_of(x, device), device)
+        out = out_u8.view(torch.int8) if x.dtype != torch.uint8 else out_u8
+        if out.dtype != x.dtype:
+            out = out.to(x.dtype)
+        out._ss_u8 = out_u8
+        return out if x.device == device else out.to(x.device)
+
+    __call__ = forward
+
+
+# ------------------------------------------------------------------------------------------------
+# the engine
+# ------------------------------------------------------------------------------------------------
+class ElphHashes(object):
+    """class to store hashes and retrieve subgraph features (mirror of reference hashing.py:48-323)"""
+
+    def __init__(self, args):
+        assert args.max_hash_hops in {1, 2, 3}, f'hashing is not implemented for {args.max_hash_hops} hops'
+        self.max_hops = args.max_hash_hops
+        self.floor_sf = args.floor_sf  # if true set minimum sf to 0
+        # minhash params (reference hashing.py:58-63)
+        self._mersenne_prime = np.uint64((1 << 61) - 1)
+        self._max_minhash = np.uint64((1 << 32) - 1)
+        self._minhash_range = (1 << 32)
+        self.minhash_seed = 1
+        self.num_perm = args.minhash_num_perm
+        self._csr_cache = _CsrCache()
+        self.minhash_prop = MinhashPropagation(self._csr_cache)
+        # hll params (reference hashing.py:65-81)
+        self.p = args.hll_p
+        self.m = 1 << self.p
+        self.use_zero_one = args.use_zero_one
+        self.label_lookup = LABEL_LOOKUP[self.max_hops]
+        self.hll_tables = hll_tables.load(self.p)
+        self.hll_hashfunc = None  # datasketch's sha1 hashfunc is never used on the path (reference :71)
+        self.alpha = self.hll_tables.alpha
+        self.max_rank = self.hll_tables.max_rank
+        assert self.max_rank == 64 - self.p, 'not using 64 bits for hll++ hashing'
+        self.hll_size = self.m
+        self.hll_threshold = self.hll_tables.threshold
+        self.bias_vector = torch.tensor(self.hll_tables.bias, dtype=torch.float)
+        self.estimate_vector = torch.tensor(self.hll_tables.raw_estimate, dtype=torch.float)
+        self.hll_prop = HllPropagation(self._csr_cache)
+        self._dev_params = {}
+        self._dev_perms = {}
+        self.strict_bounds = True  # raise IndexError for out-of-range node ids (costs one 4-byte D2H per call)
+
+    # no device handles in pickled state (SURVEY.md section 8(b) threading row)
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_dev_params'], state['_dev_perms'] = {}, {}
+        state['_csr_cache'] = None
+        state['minhash_prop'], state['hll_prop'] = None, None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._csr_cache = _CsrCache()
+        self.minhash_prop = MinhashPropagation(self._csr_cache)
+        self.hll_prop = HllPropagation(self._csr_cache)
+
+    # ---- host-side helpers -------------------------------------------------------------------------
+    def _params(self, device):
+        key = str(device)
+        if key not in self._dev_params:
+            _check_sizes(self.num_perm, self.p)
+            self._dev_params[key] = _DeviceParams(self.hll_tables, device)
+        return self._dev_params[key]
+
+    def _np_bit_length(self, bits):
+        """number of bits needed to represent each (non-negative) int in `bits` (reference :83-89), computed
+        exactly in integer arithmetic"""
+        b = np.asarray(bits).astype(np.uint64)
+        n = np.zeros(b.shape, dtype=np.int64)
+        for s in (32, 16, 8, 4, 2, 1):
+            big = b >= (np.uint64(1) << np.uint64(s))
+            n = np.where(big, n + s, n)
+            b = np.where(big, b >> np.uint64(s), b)
+        return (n + (b > 0)).astype(int)
+
+    def _get_hll_rank(self, bits):
+        """rank = leading zeros of `bits` seen as a (64 - p)-bit word, plus one (reference :91-104)"""
+        rank = self.max_rank - self._np_bit_length(bits) + 1
+        if rank.size and rank.min() <= 0:
+            raise ValueError("Hash value overflow, maximum size is %d bits" % self.max_rank)
+        return rank
+
+    def _init_permutations(self, num_perm):
+        """universal-hash parameters (a_j, b_j), j < num_perm, from numpy's legacy RandomState(seed): the draws
+        interleave a_0, b_0, a_1, b_1, ... (reference :106-116).  uint64 [2, num_perm]."""
+        gen = np.random.RandomState(self.minhash_seed)
+        ab = np.empty((2, num_perm), dtype=np.uint64)
+        for j in range(num_perm):
+            ab[0, j] = gen.randint(1, self._mersenne_prime, dtype=np.uint64)
+            ab[1, j] = gen.randint(0, self._mersenne_prime, dtype=np.uint64)
+        return ab
+
+    def _perms(self, device):
+        key = str(device)
+        if key not in self._dev_perms:
+            ab = self._init_permutations(self.num_perm).view(np.int64)
+            self._dev_perms[key] = torch.from_numpy(ab.copy()).to(device)
+        return self._dev_perms[key]
+
+    # ---- hop-0 sketches ------------------------------------------------------------------------------
+    def _init_minhash_u32(self, n_nodes, device):
+        _check_sizes(self.num_perm, self.p)
+        ab = self._perms(device)
+        out = torch.empty((n_nodes, self.num_perm), dtype=torch.int32, device=device)
+        _native.check(_native.lib().ss_minhash_init(_ptr(out), 0, n_nodes, _ptr(ab[0]), _ptr(ab[1]), self.num_perm,
+                                                    _stream(device)), 'ss_minhash_init')
+        return out
+
+    def _init_hll_u8(self, n_nodes, device):
+        _check_sizes(self.num_perm, self.p)
+        out = torch.empty((n_nodes, self.m), dtype=torch.uint8, device=device)
+        _native.check(_native.lib().ss_hll_init(_ptr(out), 0, n_nodes, self.p, _stream(device)), 'ss_hll_init')
+        return out
+
+    def initialise_minhash(self, n_nodes):
+        """int64 [n_nodes, num_perm] hop-0 MinHash rows (reference :118-124); lives on the HIP device"""
+        device = _compute_device()
+        packed = self._init_minhash_u32(n_nodes, device)
+        out = unpack_minhash(packed)
+        out._ss_u32 = packed
+        return out
+
+    def initialise_hll(self, n_nodes):
+        """int8 [n_nodes, m] hop-0 HLL rows, one non-zero register each (reference :126-137)"""
+        device = _compute_device()
+        packed = self._init_hll_u8(n_nodes, device)
+        out = packed.view(torch.int8)
+        out._ss_u8 = packed
+        return out
+
+    # ---- build ---------------------------------------------------------------------------------------
+    def build_hash_tables(self, num_nodes, edge_index):
+        """k-hop sketches of every node, k = 0..max_hops, and their HLL cardinalities (reference :139-165).
+        @return: (SketchTable {k: {'hll','minhash'}}, cards float32 [num_nodes, max_hops])"""
+        home = edge_index.device
+        device = _compute_device(edge_index)
+        params = self._params(device)
+        # add_self_loops without num_nodes (reference :148): loops for i < max(edge_index) + 1 only
+        n_self = int(edge_index.max()) + 1 if edge_index.numel() > 0 else 0
+        if n_self > num_nodes:
+            raise IndexError(f'edge_index refers to node {n_self - 1} but num_nodes is {num_nodes}')
+        csr = build_csr(edge_index, num_nodes, device)
+        csr.n_self_loops = n_self
+        cards = torch.zeros((num_nodes, self.max_hops), dtype=torch.float32, device=device)
+        table = SketchTable()
+        mh = self._init_minhash_u32(num_nodes, device)
+        hll = self._init_hll_u8(num_nodes, device)
+        table[0] = HopSketch(mh, hll, home)
+        for k in range(1, self.max_hops + 1):
+            logger.info(f"Calculating hop {k} hashes")
+            mh, hll = _propagate(csr, mh, hll, device, cards_out=cards[:, k - 1], cards_stride=self.max_hops, params=params)
+            table[k] = HopSketch(mh, hll, home)
+        return table, (cards if home == device else cards.to(home))
+
+    # ---- query ---------------------------------------------------------------------------------------
+    def _resolve_tables(self, hash_table, device):
+        mh, hll = [], []
+        for k in range(1, self.max_hops + 1):
+            entry = hash_table[k]
+            if isinstance(entry, HopSketch) and entry.mh_u32.device == device:
+                mh.append(entry.mh_u32)
+                hll.append(entry.hll_u8)
+            else:
+                mh.append(_packed_minhash_of(entry['minhash'], device))
+                hll.append(_packed_hll_of(entry['hll'], device))
+        N, P = mh[0].shape
+        for a, b in zip(mh, hll):
+            if a.shape != (N, P) or b.shape != (N, self.m):
+                raise ValueError('hash tables of different hops must have the same shape')
+        return mh, hll, N, P
+
+    def _pair_kernel(self, links, hash_table, cards, want_debug=False):
+        """runs ss_pair_features for links [B,2]; returns (features [B,nf] on device, debug dict or None)"""
+        device = _compute_device(links, cards)
+        params = self._params(device)
+        mh, hll, N, P = self._resolve_tables(hash_table, device)
+        h = self.max_hops
+        lk = links.to(device=device, dtype=torch.int64).contiguous()
+        B = lk.size(0)
+        if cards is None:
+            cd = torch.zeros((N, h), dtype=torch.float32, device=device)
+        else:
+            cd = cards.to(device=device, dtype=torch.float32)
+            if cd.dim() != 2 or cd.size(0) != N or cd.size(1) < h:
+                raise ValueError(f'cards must have shape [{N}, >= {h}], got {tuple(cd.shape)}')
+            if cd.stride(1) != 1:
+                cd = cd.contiguous()
+        nf = h * (h + 2)
+        out = torch.empty((B, nf), dtype=torch.float32, device=device)
+        dbg = None
+        err = torch.zeros(1, dtype=torch.int32, device=device)
+        if want_debug:
+            dbg = {'match': torch.empty((B, h, h), dtype=torch.int32, device=device),
+                   'zeros': torch.empty((B, h, h), dtype=torch.int32, device=device),
+                   'inter': torch.empty((B, h, h), dtype=torch.float32, device=device)}
+        mh_ptrs = (c_void_p * h)(*[t.data_ptr() for t in mh])
+        hll_ptrs = (c_void_p * h)(*[t.data_ptr() for t in hll])
+        flags = (_native.SS_FLAG_USE_ZERO_ONE if self.use_zero_one else 0) | (_native.SS_FLAG_FLOOR_SF if self.floor_sf else 0)
+        _native.check(_native.lib().ss_pair_features(
+            _ptr(lk), B, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0), byref(params.struct), flags, _ptr(out),
+            _ptr(dbg['match']) if dbg else None, _ptr(dbg['zeros']) if dbg else None, _ptr(dbg['inter']) if dbg else None,
+            _ptr(err), _stream(device)), 'ss_pair_features')
+        if self.strict_bounds and B > 0 and int(err.item()):
+            raise IndexError(f'links refer to nodes outside [-{N}, {N})')
+        return out, dbg
+
+    def _get_intersections(self, edge_list, hash_table):
+        """set-intersection estimates jaccard * union for every (k1, k2) (reference :167-189).
+        @return: {(k1, k2): float32 [n_edges]} on edge_list.device"""
+        _, dbg = self._pair_kernel(edge_list, hash_table, None, want_debug=True)
+        inter = dbg['inter'].to(edge_list.device)
+        return {(k1, k2): inter[:, k1 - 1, k2 - 1].contiguous()
+                for k1 in range(1, self.max_hops + 1) for k2 in range(1, self.max_hops + 1)}
+
+    def get_hashval(self, x):
+        return x.hashvals
+
+    def _linearcounting(self, num_zero):
+        return self.m * torch.log(self.m / num_zero)
+
+    def _estimate_bias_or_refine(self, e, refine):
+        device = _compute_device(e)
+        params = self._params(device)
+        x = e.to(device=device, dtype=torch.float32).contiguous()
+        out = torch.empty_like(x)
+        _native.check(_native.lib().ss_estimate_bias(_ptr(x), x.numel(), byref(params.struct), _ptr(out), int(refine),
+                                                     _stream(device)), 'ss_estimate_bias')
+        return out.to(e.device)
+
+    def _estimate_bias(self, e):
+        """mean bias of the 6 table entries nearest to each estimate (reference :197-204)"""
+        return self._estimate_bias_or_refine(e, False)
+
+    def _refine_hll_count_estimate(self, estimate):
+        """subtract the bias from estimates <= 5m, in place like the reference (:206-210)"""
+        refined = self._estimate_bias_or_refine(estimate, True)
+        estimate.copy_(refined)
+        return estimate
+
+    def hll_count(self, regs):
+        """HLL++ cardinality estimate of each register row (reference :212-232).
+        @param regs: integer tensor [n, m] (or [m])  @return: float32 [n] on regs.device"""
+        if regs.dim() == 1:
+            regs = regs.unsqueeze(dim=0)
+        if regs.size(1) != self.m:
+            raise ValueError(f'expected rows of {self.m} registers, got {regs.size(1)}')
+        device = _compute_device(regs)
+        params = self._params(device)
+        packed = _packed_hll_of(regs, device)
+        out = torch.empty(regs.size(0), dtype=torch.float32, device=device)
+        _native.check(_native.lib().ss_hll_count(_ptr(packed), regs.size(0), byref(params.struct), _ptr(out), 1,
+                                                 _stream(device)), 'ss_hll_count')
+        return out if regs.device == device else out.to(regs.device)
+
+    def _hll_merge(self, src, dst):
+        if src.shape != dst.shape:
+            raise ValueError('source and destination register shapes must be the same')
+        return torch.maximum(src, dst)
+
+    def hll_neighbour_merge(self, root, neighbours):
+        all_regs = torch.cat([root.unsqueeze(dim=0), neighbours], dim=0)
+        return torch.max(all_regs, dim=0)[0]
+
+    def minhash_neighbour_merge(self, root, neighbours):
+        all_regs = torch.cat([root.unsqueeze(dim=0), neighbours], dim=0)
+        return torch.min(all_regs, dim=0)[0]
+
+    def jaccard(self, src, dst):
+        """minhash Jaccard estimate of [n_edges, num_perm] hash-value tensors (reference :247-256)"""
+        if src.shape != dst.shape:
+            raise ValueError('source and destination hash value shapes must be the same')
+        return torch.count_nonzero(src == dst, dim=-1) / self.num_perm
+
+    def get_subgraph_features(self, links, hash_table, cards, batch_size=11000000):
+        """structural features of node pairs: approximations of the number of nodes at distance (d_u, d_v)
+        from (u, v), for the (d_u, d_v) listed in LABEL_LOOKUP[max_hops] (reference :258-323).
+        @param links: int tensor [n_edges, 2] (or [2])
+        @param hash_table: {hop: {'hll': [N, m], 'minhash': [N, num_perm]}} (a SketchTable or plain tensors)
+        @param cards: float tensor [N, max_hops] of neighbourhood cardinality estimates
+        @param batch_size: pairs per kernel launch (results do not depend on it)
+        @return: float32 [n_edges, max_hops * (max_hops + 2)] on links.device"""
+        if self.max_hops not in (1, 2, 3):
+            raise NotImplementedError("Only 1, 2 and 3 hop hashes are implemented")
+        if links.dim() == 1:
+            links = links.unsqueeze(0)
+        n = links.size(0)
+        if n <= batch_size:
+            feats, _ = self._pair_kernel(links, hash_table, cards)
+        else:
+            chunks = [self._pair_kernel(links[s:s + batch_size], hash_table, cards)[0] for s in range(0, n, batch_size)]
+            feats = torch.cat(chunks, dim=0)
+        return feats if feats.device == links.device else feats.to(links.device)

@@ -1,0 +1,170 @@
+"""Pins the CPU oracle (oracle/sketch_oracle.c) against golden vectors produced by importing the reference
+itself (tests/golden/make_golden.py).  Runs without a GPU.
+
+Contract: everything integer is bit-exact; floats are bit-exact on this image (the oracle follows the
+reference's fp32 operation order, including torch.sum's accumulation order) and are otherwise required to be
+within RTOL/ATOL -- torch's own low-order bits depend on the host's vector ISA."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, oracle_params
+from oracle import oracle
+
+RTOL, ATOL = 1e-5, 1e-4  # stated fp32 tolerance for cardinalities / features (values up to ~1e3)
+
+
+def _prm(tables, p):
+    return oracle_params(tables[p])
+
+
+def test_permutation_parameters():
+    g = load_golden('g1_g2_init.npz')
+    for P in (8, 128):
+        a, b = oracle.init_permutations(P)
+        assert np.array_equal(a, g[f'perm_a_P{P}']) and np.array_equal(b, g[f'perm_b_P{P}'])
+    # survey known answers
+    a, b = oracle.init_permutations(128)
+    assert [int(x) for x in a[:3]] == [775169054918279404, 2109959069025162, 401325382989534145]
+    assert [int(x) for x in b[:3]] == [1758426461858698312, 965365488286768773, 1703346441743126657]
+
+
+def test_hop0_sketches_bit_exact():
+    g = load_golden('g1_g2_init.npz')
+    assert np.array_equal(oracle.minhash_init(64, 128), g['init_mh_P128'])
+    assert np.array_equal(oracle.minhash_init(64, 8), g['init_mh_P8'])
+    assert np.array_equal(oracle.minhash_init(16, 128, first_node=100000 - 16), g['init_mh_P128_tail'])
+    for p in (4, 8, 16):
+        assert np.array_equal(oracle.hll_init(64, p), g[f'init_hll_p{p}'])
+    tail = oracle.hll_init(64, 8, first_node=100000 - 64)
+    assert np.array_equal(np.argmax(tail, axis=1), g['init_hll_p8_tail_idx'])
+    assert np.array_equal(np.max(tail, axis=1), g['init_hll_p8_tail_val'])
+    assert np.all(np.count_nonzero(tail, axis=1) == 1)
+
+
+def test_hash_matches_pandas():
+    pd_util = pytest.importorskip('pandas.util')
+    n = 5000
+    assert np.array_equal(oracle.hash_nodes(n), pd_util.hash_array(np.arange(1, n + 1)))
+
+
+def test_bit_length_formula_agrees_with_reference_float_formula():
+    """reference _np_bit_length = ceil(log2(bits + 1)) in float64 (hashing.py:89); the oracle / HIP kernels use
+    an integer clz.  They agree on every node id of the largest BASELINE config (citation2: 2.93 M nodes)."""
+    n = 2_927_963
+    hv = oracle.hash_nodes(n)
+    for p in (4, 8, 16):
+        bits = hv >> np.uint64(p)
+        float_formula = np.ceil(np.log2(bits + 1)).astype(int)
+        rank = (64 - p) - float_formula + 1
+        idx = (hv & np.uint64((1 << p) - 1)).astype(np.int64)
+        sample = slice(n - 4096, n)
+        regs = oracle.hll_init(4096, p, first_node=n - 4096)
+        assert np.array_equal(regs[np.arange(4096), idx[sample]], rank[sample].astype(np.uint8))
+        assert rank.min() >= 1 and rank.max() <= 64 - p + 1
+
+
+@pytest.mark.parametrize('h', [1, 2, 3])
+def test_ba40_tables_cards_features(regenerated_tables, h):
+    g = load_golden('g3_g4_ba40.npz')
+    prm = _prm(regenerated_tables, 8)
+    tb, cards = oracle.build_hash_tables(int(g['num_nodes']), g['edge_index'], 3, 128, prm)
+    for k in range(4):
+        assert np.array_equal(tb[k]['minhash'], g[f't_mh_{k}']), f'minhash hop {k}'
+        assert np.array_equal(tb[k]['hll'], g[f't_hll_{k}']), f'hll hop {k}'
+    assert np.array_equal(cards, g['cards'])
+    for zo in (0, 1):
+        for fl in (0, 1):
+            f, dbg = oracle.pair_features(g['links'], tb, cards[:, :h].copy(), h, prm, bool(zo), bool(fl), debug=True)
+            assert np.array_equal(dbg['match'], g[f'match_h{h}'])
+            assert np.array_equal(dbg['zeros'], g[f'zeros_h{h}'])
+            assert np.array_equal(dbg['inter'].reshape(len(f), -1), g[f'inter_h{h}'])
+            ref = g[f'feat_h{h}_zo{zo}_fl{fl}']
+            assert not g[f'feat_h{h}_zo{zo}_fl{fl}_uses_tables'].any()  # whole graph on the linear-counting branch
+            np.testing.assert_allclose(f, ref, rtol=RTOL, atol=ATOL)
+            assert np.array_equal(f, ref), 'not bit-exact against the reference on the golden host'
+    f = oracle.pair_features(g['links'], tb, cards[:, :2].copy(), 2, prm)
+    assert np.array_equal(f, g['feat_h2_batched7'])
+    assert np.array_equal(f[:1], g['feat_h2_1d'])
+
+
+@pytest.mark.parametrize('p,P', [(4, 8), (16, 128), (6, 64)])
+def test_other_parameterisations(regenerated_tables, p, P):
+    g = load_golden('g3b_params.npz')
+    prm = _prm(regenerated_tables, p)
+    tb, cards = oracle.build_hash_tables(int(g['num_nodes']), g['edge_index'], 2, P, prm)
+    key = f'p{p}P{P}'
+    for k in range(3):
+        assert np.array_equal(tb[k]['minhash'], g[f'{key}_mh_{k}'])
+        assert np.array_equal(tb[k]['hll'], g[f'{key}_hll_{k}'])
+    pinned = ~g[f'{key}_cards_uses_tables']
+    assert np.array_equal(cards[pinned], g[f'{key}_cards'][pinned])          # table-independent: bit-exact
+    np.testing.assert_allclose(cards, g[f'{key}_cards'], rtol=RTOL, atol=ATOL)  # same tables in: within fp32 tol
+    f = oracle.pair_features(g['links'], tb, cards, 2, prm)
+    np.testing.assert_allclose(f, g[f'{key}_feat'], rtol=RTOL, atol=ATOL)
+
+
+def test_hll_count_known_answers(regenerated_tables):
+    g = load_golden('g5_hll_count.npz')
+    prm = _prm(regenerated_tables, 8)
+    out, br = oracle.hll_count(g['regs'], prm, return_branch=True)
+    lc = br == 0
+    assert np.array_equal(out[lc], g['count'][lc]), 'linear-counting branch must be bit-exact'
+    # raw-estimate branches: the reference sums 2^-reg in fp32 in torch's SIMD order, the oracle sums exactly
+    np.testing.assert_allclose(out, g['count'], rtol=RTOL, atol=ATOL)
+    assert np.max(np.abs(out - g['count']) / np.maximum(g['count'], 1)) < 5e-7
+    assert np.array_equal(br == 1, g['count_uses_tables']), 'branch selection must match the reference'
+    assert set(np.unique(br)) == {0, 1, 2}, 'fixture must reach all three estimator branches'
+    # survey known answers: independent of the bias tables
+    assert out[0] == 0.0
+    assert out[1] == np.float32(1.0019733905792236)
+    assert out[2] == np.float32(216.24244689941406) and out[3] == np.float32(218.58035278320312)
+    assert br[4] == 1  # V = 108: lc = 220.94 > 220 -> estimator branch
+    assert np.array_equal(oracle.hll_count(g['regs'][1], prm), g['count_1d'])          # 1-D input -> shape [1]
+    np.testing.assert_allclose(oracle.hll_count(g['regs'].astype(np.int64), prm), g['count_int64'], rtol=RTOL, atol=ATOL)
+    assert np.array_equal(oracle.hll_count(g['regs'].astype(np.int64), prm), out)      # int64 registers accepted
+    # logf fallback (no host lc table) stays within tolerance
+    np.testing.assert_allclose(oracle.hll_count(g['regs'], oracle_params(regenerated_tables[8], with_lc=False)),
+                               g['count'], rtol=RTOL, atol=ATOL)
+
+
+def test_edge_cases_isolated_nodes_self_loops(regenerated_tables):
+    """trailing isolated nodes get no self loop -> all-zero hop>=1 rows (hashing.py:148); one-way edges"""
+    g = load_golden('g7_edge_cases.npz')
+    prm = _prm(regenerated_tables, 8)
+    n = int(g['num_nodes'])
+    tb, cards = oracle.build_hash_tables(n, g['edge_index'], 2, 128, prm)
+    for k in range(3):
+        assert np.array_equal(tb[k]['minhash'], g[f't_mh_{k}'])
+        assert np.array_equal(tb[k]['hll'], g[f't_hll_{k}'])
+    assert not tb[1]['minhash'][9:].any() and not tb[2]['hll'][9:].any()
+    assert np.array_equal(cards, g['cards'])
+    assert np.array_equal(oracle.pair_features(g['links'], tb, cards, 2, prm), g['feat'])
+    # CSR pull with implicit self loops == edge scatter with explicit ones
+    rowptr, col = oracle.csr_build(n, g['edge_index'])
+    n_self = int(g['edge_index'].max()) + 1
+    mh, hll, c = oracle.propagate_csr(n, rowptr, col, n_self, tb[0]['minhash'], tb[0]['hll'], prm)
+    assert np.array_equal(mh, tb[1]['minhash']) and np.array_equal(hll, tb[1]['hll']) and np.array_equal(c, cards[:, 0])
+
+
+@pytest.mark.parametrize('h', [2, 3])
+def test_uniform3000_reaches_bias_branch(regenerated_tables, h):
+    import hashlib
+    g = load_golden('g8_uniform3000.npz')
+    n, e_und, seed = [int(x) for x in g['graph']]
+    rng = np.random.RandomState(seed)
+    e = rng.randint(0, n, size=(2, e_und)).astype(np.int64)
+    ei = np.concatenate([e, e[::-1]], axis=1)
+    prm = _prm(regenerated_tables, 8)
+    tb, cards = oracle.build_hash_tables(n, ei, 3, 128, prm)
+    for k in range(4):
+        assert hashlib.sha256(tb[k]['hll'].tobytes()).hexdigest() == str(g[f'sha_hll_{k}'])
+        assert hashlib.sha256(tb[k]['minhash'].tobytes()).hexdigest() == str(g[f'sha_mh_{k}'])
+    pinned = ~g['cards_uses_tables']
+    assert 0.05 < g['cards_uses_tables'].mean() < 0.95
+    assert np.array_equal(cards[pinned], g['cards'][pinned])
+    np.testing.assert_allclose(cards, g['cards'], rtol=RTOL, atol=ATOL)
+    f, dbg = oracle.pair_features(g['links'], tb, cards[:, :h].copy(), h, prm, debug=True)
+    assert np.array_equal(dbg['match'], g[f'match_h{h}']) and np.array_equal(dbg['zeros'], g[f'zeros_h{h}'])
+    ref = g[f'feat_h{h}']
+    # features are differences of numbers up to ~3000: absolute tolerance scaled to the operands
+    np.testing.assert_allclose(f, ref, rtol=RTOL, atol=1e-5 * float(np.abs(g['cards']).max()) * 4)
