@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, on N MI355X of one node.
+
+metric   : edge-pairs/sec subgraph-feature extraction (build+query)
+workload : configs[1] "ogbl-collab, BUDDY, max_hash_hops=2, batch_size=65536" as a synthetic graph of the same
+           shape: N=235 868 nodes, E_und=1 179 052 uniform-random undirected edges
+           (seed 1, both directions -> E_dir=2 358 104), P=128, p=8, h=2; one batch of B=65 536 node pairs per
+           step and per GPU (seed 2+rank).
+step     : one pass of the whole hot path over one batch: ElphHashes.build_hash_tables (CSR build, hop-0
+           sketches, h propagation hops with fused cardinalities) + ElphHashes.get_subgraph_features(B pairs),
+           i.e. what ELPH does per training step (reference runners/train.py:198,204) and what BUDDY does once
+           per edge set.  Nothing is cached between steps.  Inputs (edge_index, links) are resident in HBM.
+N > 1    : one process per GPU (torchrun), sketch table replicated (every rank builds it), edge batches
+           sharded -- each rank owns its own B pairs -- and the per-batch feature rows all-gathered over
+           RCCL (all_gather_into_tensor, inside the timed region).  Weak scaling.
+roofline : dominant kernel = ss::propagate_kernel (one launch per hop).  achieved = algorithmic bytes per
+           launch ((E'+N)*768 + 4E' + 8(N+1) + 4N, E' = E_dir + N) / mean launch
+           duration measured live in the timed region with HIP events on the launch stream.
+cpu_baseline : the oracle's C port (oracle/sketch_oracle.c, OpenMP on all host cores) timed on ONE full step
+           of the same workload, rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_NODES, E_UND, H, P, HLL_P, BATCH = 235868, 1179052, 2, 128, 8, 65536
+ROW_BYTES = 4 * P + (1 << HLL_P)
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_graph(seed=1):
+    rng = np.random.RandomState(seed)
+    e = rng.randint(0, N_NODES, size=(2, E_UND)).astype(np.int64)
+    return np.concatenate([e, e[::-1]], axis=1)
+
+
+def synthetic_links(seed):
+    return np.random.RandomState(seed).randint(0, N_NODES, size=(BATCH, 2)).astype(np.int64)
+
+
+class KernelTimer(object):
+    """HIP-event pairs around the engine's launches, on the stream they are launched on"""
+
+    def __init__(self):
+        self.events = {}
+
+    def record(self, name, stream):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
+
+    def span(self, name, start, end):
+        self.events.setdefault(name, []).append((start, end))
+
+    def mean_ms(self, name):
+        spans = self.events.get(name, [])
+        return sum(a.elapsed_time(b) for a, b in spans) / max(len(spans), 1), len(spans)
+
+
+def cpu_baseline(ei, links):
+    """oracle C port (OpenMP) on one full step; returns the cpu_baseline object"""
+    import subgraph_sketching_amd as ssa
+    from oracle import oracle
+    t = ssa.hll_tables.load(HLL_P)
+    prm = oracle.HllParams(t.p, t.threshold, t.raw_estimate, t.bias, alpha=t.alpha,
+                           lc_table=ssa.hashing.linear_counting_table(1 << t.p).numpy())
+    cores = os.cpu_count()
+    oracle.lib()
+    t0 = time.perf_counter()
+    rowptr, col = oracle.csr_build(N_NODES, ei)
+    n_self = int(ei.max()) + 1
+    mh, hll = oracle.minhash_init(N_NODES, P), oracle.hll_init(N_NODES, HLL_P)
+    tables, cards = {0: {'minhash': mh, 'hll': hll}}, np.zeros((N_NODES, H), dtype=np.float32)
+    for k in range(1, H + 1):
+        mh, hll, c = oracle.propagate_csr(N_NODES, rowptr, col, n_self, mh, hll, prm)
+        tables[k] = {'minhash': mh, 'hll': hll}
+        cards[:, k - 1] = c
+    t1 = time.perf_counter()
+    feats = oracle.pair_features(links, tables, cards, H, prm)
+    t2 = time.perf_counter()
+    return {'value': BATCH / (t2 - t0), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 full step (build N={N_NODES}, E_dir={2 * E_UND}, h={H} + {BATCH} pairs); '
+                      f'build {t1 - t0:.2f} s, query {t2 - t1:.3f} s; C/OpenMP restatement of the reference, '
+                      f'not the torch/PyG code itself'}, feats
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+    assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {a.gpus}'
+
+    import subgraph_sketching_amd as ssa
+    from subgraph_sketching_amd import hashing
+    ssa._native.lib()  # fail loudly if the HIP engine is missing
+    eh = ssa.ElphHashes(Namespace(max_hash_hops=H, hll_p=HLL_P, minhash_num_perm=P, floor_sf=False, use_zero_one=True))
+    eh.strict_bounds = False  # no host sync inside a step
+
+    ei_np = synthetic_graph()
+    links_np = synthetic_links(2 + rank)
+    ei = torch.from_numpy(ei_np).to(dev)
+    links = torch.from_numpy(links_np).to(dev)
+    gathered = torch.empty((world * BATCH, H * (H + 2)), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        table, cards = eh.build_hash_tables(N_NODES, ei)
+        f = eh.get_subgraph_features(links, table, cards)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, f)
+        return f
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        feats = step()
+    timer = KernelTimer()
+    hashing.KERNEL_TIMER = timer
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        feats = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    hashing.KERNEL_TIMER = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    prop_ms, prop_n = timer.mean_ms('propagate')
+    pair_ms, pair_n = timer.mean_ms('pair_features')
+    csr_ms, _ = timer.mean_ms('csr_build')
+    e_prime = 2 * E_UND + N_NODES
+    prop_bytes = (e_prime + N_NODES) * ROW_BYTES + 4 * e_prime + 8 * (N_NODES + 1) + 4 * N_NODES
+    pair_bytes = BATCH * (2 * H * ROW_BYTES + 16 + 8 * H + 4 * H * (H + 2))
+    traffic = None
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as fh:
+            traffic = json.load(fh).get('propagate_kernel_hbm_bytes_per_launch')
+
+    out = {
+        'metric': 'edge-pairs/sec subgraph-feature extraction (build+query)',
+        'value': world * BATCH * a.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps,
+        'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'u32/u8 sketches, f32 estimator', 'data': 'synthetic',
+        'config': {'workload': 'ogbl-collab-like synthetic graph (BASELINE configs[1]), BUDDY/ELPH hot path: step = '
+                               'build_hash_tables + get_subgraph_features, nothing cached across steps',
+                   'num_nodes': N_NODES, 'directed_edges': 2 * E_UND, 'max_hash_hops': H, 'minhash_num_perm': P, 'hll_p': HLL_P,
+                   'pairs_per_step_per_gpu': BATCH, 'global_pairs_per_step': world * BATCH,
+                   'parallelism': f'edge-batch sharded x{world}, sketch table replicated, all_gather of features',
+                   'hll_tables': eh.hll_tables.provenance},
+        'roofline': {'kernel': 'ss::propagate_kernel<128,256>', 'bound': 'hbm', 'achieved': prop_bytes / (prop_ms * 1e-3) / 1e9 if prop_ms else None,
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': prop_bytes / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if prop_ms else None, 'traffic': traffic,
+                     'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n},
+        'kernels': {'propagate_ms_per_launch': prop_ms, 'pair_features_ms_per_launch': pair_ms, 'csr_build_ms': csr_ms,
+                    'pair_features_algorithmic_bytes': pair_bytes,
+                    'pair_features_GBps': pair_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms else None,
+                    'pair_features_frac_of_hbm_peak': pair_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pair_ms else None,
+                    'query_only_pairs_per_s': BATCH / (pair_ms * 1e-3) if pair_ms else None},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        base, ofeat = cpu_baseline(ei_np, links_np)
+        out['cpu_baseline'] = base
+        diff = float(np.abs(feats.cpu().numpy() - ofeat).max())
+        out['cpu_baseline']['max_abs_feature_diff_vs_gpu'] = diff
+        out['speedup_vs_cpu_baseline'] = out['value'] / base['value']
+    elif rank == 0:
+        out['cpu_baseline'] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -33,6 +33,25 @@ LABEL_LOOKUP = {1: {0: (1, 1), 1: (0, 1), 2: (1, 0)},
 # ------------------------------------------------------------------------------------------------
 # device plumbing
 # ------------------------------------------------------------------------------------------------
+KERNEL_TIMER = None  # bench.py installs an object with record(name, stream) / span(name, start, end)
+
+
+class _Span(object):
+    """optional HIP-event bracket around a launch, recorded on the launch stream"""
+
+    def __init__(self, name, device):
+        self.name, self.device, self.timer = name, device, KERNEL_TIMER
+
+    def __enter__(self):
+        if self.timer is not None:
+            self.start = self.timer.record(self.name, torch.cuda.current_stream(self.device))
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.span(self.name, self.start, self.timer.record(self.name, torch.cuda.current_stream(self.device)))
+        return False
+
+
 def _compute_device(*tensors):
     """the HIP device the kernels run on: the device of the first GPU tensor, else the current one"""
     for t in tensors:
@@ -214,8 +233,9 @@ def build_csr(edge_index, num_nodes, device, check=True):
     err = torch.zeros(1, dtype=torch.int32, device=device)
     ws_bytes = lib.ss_csr_workspace_bytes(num_nodes, E)
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
-    _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(err), _ptr(ws),
-                                   ws_bytes, _stream(device)), 'ss_csr_build')
+    with _Span('csr_build', device):
+        _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(err), _ptr(ws),
+                                       ws_bytes, _stream(device)), 'ss_csr_build')
     if check and int(err.item()):
         raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
     return CsrGraph(rowptr, col, num_nodes, 0)
@@ -250,9 +270,10 @@ def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, param
     P = mh_in.size(1) if mh_in is not None else 0
     M = hll_in.size(1) if hll_in is not None else 0
     prm = byref(params.struct) if params is not None else None
-    _native.check(_native.lib().ss_propagate(_ptr(csr.rowptr), _ptr(csr.col), N, csr.n_self_loops, _ptr(mh_in), _ptr(mh_out),
-                                             P, _ptr(hll_in), _ptr(hll_out), M, _ptr(cards_out), cards_stride, prm,
-                                             _stream(device)), 'ss_propagate')
+    with _Span('propagate', device):
+        _native.check(_native.lib().ss_propagate(_ptr(csr.rowptr), _ptr(csr.col), N, csr.n_self_loops, _ptr(mh_in),
+                                                 _ptr(mh_out), P, _ptr(hll_in), _ptr(hll_out), M, _ptr(cards_out),
+                                                 cards_stride, prm, _stream(device)), 'ss_propagate')
     return mh_out, hll_out
 
 
@@ -492,10 +513,11 @@ class ElphHashes(object):
         mh_ptrs = (c_void_p * h)(*[t.data_ptr() for t in mh])
         hll_ptrs = (c_void_p * h)(*[t.data_ptr() for t in hll])
         flags = (_native.SS_FLAG_USE_ZERO_ONE if self.use_zero_one else 0) | (_native.SS_FLAG_FLOOR_SF if self.floor_sf else 0)
-        _native.check(_native.lib().ss_pair_features(
-            _ptr(lk), B, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0), byref(params.struct), flags, _ptr(out),
-            _ptr(dbg['match']) if dbg else None, _ptr(dbg['zeros']) if dbg else None, _ptr(dbg['inter']) if dbg else None,
-            _ptr(err), _stream(device)), 'ss_pair_features')
+        with _Span('pair_features', device):
+            _native.check(_native.lib().ss_pair_features(
+                _ptr(lk), B, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0), byref(params.struct), flags, _ptr(out),
+                _ptr(dbg['match']) if dbg else None, _ptr(dbg['zeros']) if dbg else None,
+                _ptr(dbg['inter']) if dbg else None, _ptr(err), _stream(device)), 'ss_pair_features')
         if self.strict_bounds and B > 0 and int(err.item()):
             raise IndexError(f'links refer to nodes outside [-{N}, {N})')
         return out, dbg
