@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/subgraph_sketch.h declares
+(no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, 'include', 'subgraph_sketch.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ss_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_the_expected_boundary():
+    names = _declared_symbols()
+    for needed in ('ss_minhash_init', 'ss_hll_init', 'ss_csr_build', 'ss_propagate', 'ss_hll_count', 'ss_pair_features',
+                   'ss_pack_minhash', 'ss_unpack_minhash', 'ss_estimate_bias', 'ss_version', 'ss_error_string'):
+        assert needed in names
+
+
+def test_library_exports_every_declared_symbol():
+    import subgraph_sketching_amd as ssa
+    path = ssa._native.LIB_PATH
+    assert os.path.exists(path), 'run `python __graft_entry__.py` first (build())'
+    handle = ctypes.CDLL(path)
+    declared = _declared_symbols()
+    missing = [n for n in declared if not hasattr(handle, n)]
+    assert not missing, f'symbols declared in the header but not exported: {missing}'
+    unbound = [n for n in declared if n not in ssa._native.SIGNATURES]
+    assert not unbound, f'symbols declared in the header but not bound in _native.SIGNATURES: {unbound}'
+    extra = [n for n in ssa._native.SIGNATURES if n not in declared]
+    assert not extra, f'bound but not declared: {extra}'
+
+
+def test_version_and_error_strings():
+    import subgraph_sketching_amd as ssa
+    lib = ssa._native.lib()
+    assert lib.ss_version() == 100
+    assert lib.ss_error_string(0) == b'ok'
+    assert b'invalid' in lib.ss_error_string(-1)
+    assert lib.ss_csr_workspace_bytes(1000, 5000) >= 8 * 1001
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    """argument validation happens on the host before any launch"""
+    import subgraph_sketching_amd as ssa
+    lib = ssa._native.lib()
+    assert lib.ss_minhash_init(None, 0, 10, None, None, 128, None) == -1      # null pointers
+    assert lib.ss_minhash_init(None, 0, 0, None, None, 128, None) == 0        # empty is fine
+    assert lib.ss_hll_init(None, 0, 10, 3, None) == -1                        # p < 4
+    assert lib.ss_pack_minhash(None, None, -1, None) == -1
+    assert lib.ss_pair_features(None, 0, 0, 4, None, 128, None, None, 0, None, 0, None, None, None, None, None, None) == -4  # h = 4
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import subgraph_sketching_amd as ssa
+    monkeypatch.setattr(ssa._native, '_lib', None)
+    monkeypatch.setattr(ssa._native, 'LIB_PATH', '/nonexistent/libsubgraph_sketch.so')
+    with pytest.raises(ssa._native.NativeLibraryMissing):
+        ssa._native.lib()

@@ -1,0 +1,139 @@
+"""Host-side logic of the ElphHashes mirror that needs no GPU: constants, constructor contract, parameter
+derivation, containers, sharding arithmetic -- and that compute entry points refuse to run without a HIP device."""
+import pickle
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+no_gpu = not torch.cuda.is_available()
+
+
+def _args(h=2, p=8, P=128, floor_sf=False, use_zero_one=True):
+    return Namespace(max_hash_hops=h, hll_p=p, minhash_num_perm=P, floor_sf=floor_sf, use_zero_one=use_zero_one)
+
+
+@pytest.fixture(scope='module')
+def ssa():
+    import subgraph_sketching_amd as m
+    return m
+
+
+def test_label_lookup(ssa):
+    for key, val in ssa.LABEL_LOOKUP.items():  # reference test_hashing.py:196-198
+        assert len(val) == key * (key + 2)
+    assert ssa.LABEL_LOOKUP[2][7] == (2, 0) and ssa.LABEL_LOOKUP[3][4] == (3, 1) and ssa.LABEL_LOOKUP[3][12] == (2, 0)
+
+
+def test_constructor_contract(ssa):
+    eh = ssa.ElphHashes(_args())
+    assert eh.max_hops == 2 and eh.num_perm == 128 and eh.p == 8 and eh.m == 256 and eh.hll_size == 256
+    assert eh.max_rank == 56 and int(eh._max_minhash) == 2 ** 32 - 1 and int(eh._mersenne_prime) == 2 ** 61 - 1
+    assert eh.minhash_seed == 1 and eh.label_lookup is ssa.LABEL_LOOKUP[2] and eh.hll_threshold == 220
+    assert abs(eh.alpha - 0.7182725932495458) < 1e-15
+    assert eh.bias_vector.dtype == torch.float32 and eh.estimate_vector.shape == eh.bias_vector.shape
+    assert callable(eh.hll_prop) and callable(eh.minhash_prop)
+    for bad in (0, 4):
+        with pytest.raises(AssertionError):
+            ssa.ElphHashes(_args(h=bad))
+    eh3 = ssa.ElphHashes(_args(h=3, p=4, P=8))
+    assert eh3.m == 16 and eh3.max_rank == 60 and eh3.hll_threshold == 10 and eh3.alpha == 0.673
+
+
+def test_bit_length_and_rank(ssa):
+    eh = ssa.ElphHashes(_args())
+    arr = np.arange(1000)
+    for bl, elem in zip(eh._np_bit_length(arr), arr):  # reference test_hashing.py:331-336
+        assert int(elem).bit_length() == bl
+    big = np.array([2 ** 53 - 1, 2 ** 53, 2 ** 53 + 1, 2 ** 55 + 1, 2 ** 56 - 1], dtype=np.uint64)
+    assert list(eh._np_bit_length(big)) == [int(x).bit_length() for x in big]
+    assert list(eh._get_hll_rank(np.array([0, 1, 2 ** 55], dtype=np.uint64))) == [57, 56, 1]
+    with pytest.raises(ValueError):
+        eh._get_hll_rank(np.array([2 ** 56], dtype=np.uint64))
+
+
+def test_permutations_match_reference(ssa):
+    g = load_golden('g1_g2_init.npz')
+    for P in (8, 128):
+        ab = ssa.ElphHashes(_args(P=P))._init_permutations(P)
+        assert ab.dtype == np.uint64 and ab.shape == (2, P)
+        assert np.array_equal(ab[0], g[f'perm_a_P{P}']) and np.array_equal(ab[1], g[f'perm_b_P{P}'])
+
+
+def test_linear_counting_table_and_threshold(ssa):
+    lc = ssa.hashing.linear_counting_table(256).numpy()
+    assert lc.shape == (257,) and lc[256] == 0.0 and np.all(np.diff(lc[1:]) < 0)
+    assert abs(lc[110] - 216.24244689941406) < 1e-4 and abs(lc[109] - 218.58035278320312) < 1e-4
+    ok = lc[1:] <= np.float32(220)
+    assert int(np.argmax(ok)) + 1 == 109  # p=8: linear counting iff V >= 109 zero registers
+
+
+def test_hll_tables_provider(ssa):
+    for p in (4, 8, 16):
+        t = ssa.hll_tables.load(p, prefer='regenerated')
+        assert t.provenance == 'regenerated' and t.max_rank == 64 - p
+        assert 6 <= len(t.raw_estimate) <= 512 and len(t.raw_estimate) == len(t.bias)
+        assert np.all(np.diff(t.raw_estimate) >= 0)
+        m = 1 << p
+        assert abs(t.raw_estimate[0] - t.alpha * m) < 1e-6 * m    # zero items: raw estimate = alpha*m
+        assert abs(t.bias[0] - t.raw_estimate[0]) < 1e-9
+        assert 4.9 * m < t.raw_estimate[-1] < 5.4 * m
+    with pytest.raises(ValueError):
+        ssa.hll_tables.load(3)
+    assert ssa.hll_tables.load(8).provenance in ('datasketch', 'regenerated')
+
+
+def test_shard_bounds(ssa):
+    for L in (0, 1, 7, 64, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [ssa.dist.shard_bounds(L, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == L
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) <= (L + world - 1) // world
+
+
+def test_engine_pickles_without_device_state(ssa):
+    eh = ssa.ElphHashes(_args())
+    eh._dev_params['cuda:0'] = object()  # would not pickle
+    clone = pickle.loads(pickle.dumps(eh))
+    assert clone.max_hops == 2 and clone._dev_params == {} and callable(clone.hll_prop)
+
+
+def test_thin_torch_helpers(ssa):
+    eh = ssa.ElphHashes(_args())
+    a = torch.tensor([[1, 2, 3, 4]] * 2)
+    assert torch.equal(eh._hll_merge(a, a + 1), a + 1)
+    with pytest.raises(ValueError):
+        eh._hll_merge(torch.zeros(2, 4), torch.zeros(3, 4))
+    with pytest.raises(ValueError):
+        eh.jaccard(torch.zeros(2, 4), torch.zeros(2, 5))
+    eh.num_perm = 4
+    assert torch.allclose(eh.jaccard(a, torch.tensor([[1, 2, 0, 0], [1, 2, 3, 4]])), torch.tensor([0.5, 1.0]))
+    root, nb = torch.tensor([3, 1]), torch.tensor([[2, 5], [4, 0]])
+    assert torch.equal(eh.hll_neighbour_merge(root, nb), torch.tensor([4, 5]))
+    assert torch.equal(eh.minhash_neighbour_merge(root, nb), torch.tensor([2, 0]))
+
+
+@pytest.mark.skipif(not no_gpu, reason='only meaningful on a GPU-less host')
+def test_no_cpu_fallback(ssa):
+    """the product path must fail loudly when there is no HIP device -- never compute on the CPU"""
+    eh = ssa.ElphHashes(_args())
+    ei = torch.tensor([[0, 1], [1, 0]])
+    for call in (lambda: eh.initialise_minhash(4), lambda: eh.initialise_hll(4), lambda: eh.build_hash_tables(2, ei),
+                 lambda: eh.hll_count(torch.zeros(2, 256, dtype=torch.int8)),
+                 lambda: eh.hll_prop(torch.zeros(2, 256, dtype=torch.int8), ei),
+                 lambda: eh.minhash_prop(torch.zeros(2, 128, dtype=torch.int64), ei),
+                 lambda: eh.get_subgraph_features(torch.tensor([[0, 1]]), {1: {}, 2: {}}, torch.zeros(2, 2))):
+        with pytest.raises(RuntimeError, match='HIP device'):
+            call()
+
+
+def test_unsupported_sizes_raise(ssa):
+    with pytest.raises(NotImplementedError):
+        ssa.hashing._check_sizes(6, 8)
+    with pytest.raises(NotImplementedError):
+        ssa.hashing._check_sizes(128, 17)
