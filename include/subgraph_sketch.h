@@ -76,20 +76,25 @@ int ss_hll_init(uint8_t *out, int64_t first_node, int64_t n, int32_t p, void *st
  * torch_geometric MessagePassing.propagate as used by hashing.py:34,44 (flow source -> target).
  *   src/dst: device int64[E] (edge_index[0], edge_index[1]);  rowptr: device int64[N+1];
  *   col: device int32[E] (source ids grouped by destination, order inside a row unspecified).
- *   err_flag: device int32, set to 1 if any endpoint is outside [0, N) (such edges are dropped).
- * Workspace: ss_csr_workspace_bytes(N, E) bytes. */
+ *   n_self_loops_out: device int64 (nullable) <- max(edge_index) + 1 (0 for E == 0): the number of self loops
+ *   torch_geometric.utils.add_self_loops(edge_index) appends when num_nodes is not given (hashing.py:148), so
+ *   the host never has to synchronise on edge_index.max().
+ *   err_flag: device int32 (nullable), set to 1 if any endpoint is outside [0, N) (such edges are dropped).
+ * Workspace: ss_csr_workspace_bytes(N, E) bytes (0 = unsupported size).  No per-edge global atomics: a
+ * two-level counting sort (LDS histograms per edge slice -> bucket offsets -> per-bucket LDS sort). */
 size_t ss_csr_workspace_bytes(int64_t N, int64_t E);
 int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
-                 int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream);
+                 int64_t *n_self_loops_out, int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream);
 
 /* One hop of sketch propagation over a CSR: out[i] = min (MinHash) / max (HLL) over the in-neighbours
  * of i, plus row i itself when i < n_self_loops (the implicit self loops of add_self_loops,
  * hashing.py:148); rows with no in-edge and no self loop are all-zero (PyG scatter default).
  * Replaces MinhashPropagation.forward / HllPropagation.forward (hashing.py:28-45) and, when
  * cards_out != NULL, the hll_count of hashing.py:163 (cards_out[i*cards_stride] = hll_count(out row)).
- * Either sketch may be NULL (both in and out). */
+ * Either sketch may be NULL (both in and out).  n_self_loops_dev (device int64, nullable) overrides the
+ * scalar n_self_loops when given (the value ss_csr_build produced, read by the kernel itself). */
 int ss_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
-                 const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
+                 const int64_t *n_self_loops_dev, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
                  const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
                  float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream);
 
@@ -127,7 +132,7 @@ int ss_unpack_minhash(const uint32_t *in, int64_t *out, int64_t count, void *str
  * same ss_propagate / ss_pair_features call ON `stream` and returns the mean milliseconds per launch in
  * *ms_out (host pointer).  Synchronises the stream. */
 int ss_time_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
-                      const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
+                      const int64_t *n_self_loops_dev, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
                       const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
                       float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream,
                       int32_t reps, float *ms_out);

@@ -30,9 +30,9 @@ SIGNATURES = {
     'ss_minhash_init': (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]),
     'ss_hll_init': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'ss_csr_workspace_bytes': (c_size_t, [c_int64, c_int64]),
-    'ss_csr_build': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                               c_void_p]),
-    'ss_propagate': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+    'ss_csr_build': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_size_t, c_void_p]),
+    'ss_propagate': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p]),
     'ss_hll_count': (c_int32, [c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int64, c_void_p]),
     'ss_estimate_bias': (c_int32, [c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int32, c_void_p]),
@@ -41,7 +41,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p]),
     'ss_pack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_unpack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
-    'ss_time_propagate': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p,
+    'ss_time_propagate': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                     c_void_p, c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int32,
                                     POINTER(c_float)]),
     'ss_time_pair_features': (c_int32, [c_void_p, c_int64, c_int64, c_int32, POINTER(c_void_p), c_int32,

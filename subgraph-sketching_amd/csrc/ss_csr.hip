@@ -1,77 +1,133 @@
 // ss_csr.hip -- CSR-by-destination construction on the device.
 //
 // The reference materialises one message x[src] per edge and scatter-maxes it (PyG propagate,
-// hashing.py:34,44).  The MI355X engine instead pulls: rows are grouped by destination once and every
-// hop streams whole neighbour rows.  Construction = degree histogram (atomics) -> exclusive scan ->
-// cursor fill (atomics).  The order of sources inside a row is unspecified; min/max do not care.
+// hashing.py:34,44).  The MI355X engine instead pulls: edges are grouped by destination once and every
+// hop streams whole neighbour rows.  The order of sources inside a row is unspecified (min / max do not
+// care), which lets the build be a two-level counting sort with NO per-edge global atomics -- on gfx950
+// device-scope atomics from 8 non-coherent XCD L2s are served at the memory side and cost ~45 ns per
+// 1000 edges each way (first version: 0.23 ms for 2.4 M edges, profiles/round1_v1_kernel_stats.csv).
+//
+//   A1 bucket_count   : each block takes a contiguous slice of the edge list, histograms dst >> shift in
+//                       LDS (a bucket = NB consecutive nodes), writes its row of the [blocks x buckets]
+//                       count matrix; also validates ids and reduces max(id)+1 (= self-loop count of
+//                       add_self_loops, hashing.py:148).
+//   A2 bucket_offsets : per bucket, exclusive scan over blocks (column of the matrix) + bucket totals.
+//   A3 bucket_bases   : single block, exclusive scan of bucket totals -> bucket base offsets.
+//   A4 bucket_scatter : same slices as A1; LDS cursors seeded with base[bucket] + offset[block][bucket];
+//                       edges are written as (src, dst) int32 pairs grouped by bucket.
+//   B  bucket_finish  : one block per bucket: LDS histogram over its NB nodes, LDS scan -> rowptr,
+//                       LDS cursors -> col.
 #include "ss_common.hpp"
 
 namespace ss {
 
-constexpr int kScanBlock = 256;
-constexpr int kScanItems = 8;                        // items per thread
-constexpr int kScanTile = kScanBlock * kScanItems;   // 2048 counters per block
+constexpr int kCsrThreads = 256;
+constexpr int kEdgesPerBlockMin = 4096;   // slice size lower bound (A1 / A4)
+constexpr int kMaxSliceBlocks = 1024;
+constexpr int kMaxBuckets = 4096;         // LDS histogram size of A1 / A4
+constexpr int kMinNodesPerBucket = 1024;
+constexpr int kMaxNodesPerBucket = 16384; // LDS of B: 2 * NB * 4 bytes
+constexpr int kFinishThreads = 1024;
 
-__global__ __launch_bounds__(256) void degree_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                                                     int64_t E, int64_t N, unsigned long long *__restrict__ deg,
-                                                     int32_t *__restrict__ err)
+struct CsrPlan {
+    int shift;         // bucket = dst >> shift
+    int nodes_per_bucket;
+    int buckets;
+    int slice_blocks;
+    int64_t slice_edges;
+};
+
+inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
 {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    int nb = kMinNodesPerBucket, shift = 10;
+    while ((N + nb - 1) / nb > kMaxBuckets && nb < kMaxNodesPerBucket) { nb <<= 1; ++shift; }
+    if ((N + nb - 1) / nb > kMaxBuckets) return false;
+    p.shift = shift;
+    p.nodes_per_bucket = nb;
+    p.buckets = (int)((N + nb - 1) / nb);
+    if (p.buckets < 1) p.buckets = 1;
+    int64_t blocks = (E + kEdgesPerBlockMin - 1) / kEdgesPerBlockMin;
+    if (blocks < 1) blocks = 1;
+    if (blocks > kMaxSliceBlocks) blocks = kMaxSliceBlocks;
+    p.slice_blocks = (int)blocks;
+    p.slice_edges = (E + blocks - 1) / blocks;
+    return true;
+}
+
+__global__ __launch_bounds__(kCsrThreads) void bucket_count_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                                   int64_t E, int64_t N, int shift, int buckets, int64_t slice_edges,
+                                                                   uint32_t *__restrict__ counts /*[blocks][buckets]*/,
+                                                                   unsigned long long *__restrict__ n_self /* max id + 1 */,
+                                                                   int32_t *__restrict__ err)
+{
+    __shared__ uint32_t hist[kMaxBuckets];
+    __shared__ unsigned long long block_max;
+    for (int b = threadIdx.x; b < buckets; b += blockDim.x) hist[b] = 0;
+    if (threadIdx.x == 0) block_max = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * slice_edges;
+    const int64_t hi = lo + slice_edges < E ? lo + slice_edges : E;
+    unsigned long long my_max = 0;
+    bool bad = false;
+    for (int64_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
         const int64_t s = src[e], d = dst[e];
         if ((uint64_t)s >= (uint64_t)N || (uint64_t)d >= (uint64_t)N) {
-            if (err) *err = 1;
+            bad = true;
+            // ids beyond N still count for the self-loop inference so the host can report them
+            const int64_t mx = s > d ? s : d;
+            if (mx >= 0 && (unsigned long long)mx + 1 > my_max) my_max = (unsigned long long)mx + 1;
             continue;
         }
-        atomicAdd(&deg[d], 1ULL);
+        const unsigned long long mx = (unsigned long long)(s > d ? s : d) + 1;
+        my_max = mx > my_max ? mx : my_max;
+        atomicAdd(&hist[d >> shift], 1u);
     }
-}
-
-// block-local exclusive scan of a 2048-counter tile; writes tile totals
-__global__ __launch_bounds__(kScanBlock) void scan_tiles_kernel(const unsigned long long *__restrict__ deg, int64_t N,
-                                                                int64_t *__restrict__ rowptr,
-                                                                unsigned long long *__restrict__ tile_sum)
-{
-    __shared__ unsigned long long wave_tot[kScanBlock / kWave];
-    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-    unsigned long long v[kScanItems], run = 0;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        v[k] = (base + k < N) ? deg[base + k] : 0ULL;
-        run += v[k];
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(my_max, off);
+        my_max = o > my_max ? o : my_max;
     }
-    // inclusive scan of per-thread totals across the wave
-    unsigned long long inc = run;
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const unsigned long long o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-    }
-    if (lane == kWave - 1) wave_tot[wv] = inc;
+    if ((threadIdx.x & (kWave - 1)) == 0 && my_max) atomicMax(&block_max, my_max);
+    if (bad && err) *err = 1;
     __syncthreads();
-    unsigned long long pre = 0;
-    for (int w = 0; w < wv; ++w) pre += wave_tot[w];
-    unsigned long long ex = pre + inc - run;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        if (base + k < N) rowptr[base + k] = (int64_t)ex;
-        ex += v[k];
-    }
-    if (threadIdx.x == kScanBlock - 1) tile_sum[blockIdx.x] = pre + inc;
+    for (int b = threadIdx.x; b < buckets; b += blockDim.x) counts[(int64_t)blockIdx.x * buckets + b] = hist[b];
+    if (threadIdx.x == 0 && block_max) atomicMax(n_self, block_max);
 }
 
-// single block: exclusive scan of the tile totals in place; writes the grand total to rowptr[N]
-__global__ __launch_bounds__(kScanBlock) void scan_totals_kernel(unsigned long long *__restrict__ tile_sum, int64_t tiles,
-                                                                 int64_t *__restrict__ rowptr, int64_t N)
+// one wave per bucket: exclusive scan of the bucket's column over slice blocks (in place), bucket total out
+__global__ __launch_bounds__(kCsrThreads) void bucket_offsets_kernel(uint32_t *__restrict__ counts, int slice_blocks, int buckets,
+                                                                     unsigned long long *__restrict__ bucket_total)
 {
-    __shared__ unsigned long long wave_tot[kScanBlock / kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int b = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (b >= buckets) return;
+    uint32_t carry = 0;
+    for (int g0 = 0; g0 < slice_blocks; g0 += kWave) {
+        const int g = g0 + lane;
+        const uint32_t x = g < slice_blocks ? counts[(int64_t)g * buckets + b] : 0u;
+        uint32_t inc = x;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (g < slice_blocks) counts[(int64_t)g * buckets + b] = carry + inc - x;
+        carry += __shfl(inc, kWave - 1);
+    }
+    if (lane == 0) bucket_total[b] = carry;
+}
+
+// single block: exclusive scan of bucket totals in place (-> bucket bases); grand total to rowptr[N]
+__global__ __launch_bounds__(kCsrThreads) void bucket_bases_kernel(unsigned long long *__restrict__ bucket_total, int buckets,
+                                                                   int64_t *__restrict__ rowptr, int64_t N)
+{
+    __shared__ unsigned long long wave_tot[kCsrThreads / kWave];
     __shared__ unsigned long long carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    for (int64_t start = 0; start < tiles; start += kScanBlock) {
-        const int64_t i = start + threadIdx.x;
-        const unsigned long long x = i < tiles ? tile_sum[i] : 0ULL;
+    for (int start = 0; start < buckets; start += kCsrThreads) {
+        const int i = start + threadIdx.x;
+        const unsigned long long x = i < buckets ? bucket_total[i] : 0ULL;
         unsigned long long inc = x;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
@@ -82,84 +138,141 @@ __global__ __launch_bounds__(kScanBlock) void scan_totals_kernel(unsigned long l
         __syncthreads();
         unsigned long long pre = carry_s;
         for (int w = 0; w < wv; ++w) pre += wave_tot[w];
-        if (i < tiles) tile_sum[i] = pre + inc - x;
+        if (i < buckets) bucket_total[i] = pre + inc - x;
         __syncthreads();
-        if (threadIdx.x == kScanBlock - 1) carry_s = pre + inc;
+        if (threadIdx.x == kCsrThreads - 1) carry_s = pre + inc;
         __syncthreads();
     }
     if (threadIdx.x == 0) rowptr[N] = (int64_t)carry_s;
 }
 
-__global__ __launch_bounds__(256) void add_tile_offsets_kernel(int64_t *__restrict__ rowptr, int64_t N,
-                                                               const unsigned long long *__restrict__ tile_sum)
+__global__ __launch_bounds__(kCsrThreads) void bucket_scatter_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                                     int64_t E, int64_t N, int shift, int buckets, int64_t slice_edges,
+                                                                     const uint32_t *__restrict__ offsets /*[blocks][buckets]*/,
+                                                                     const unsigned long long *__restrict__ bucket_base,
+                                                                     int2 *__restrict__ staged /*[E] (src, dst)*/)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
-        rowptr[i] += (int64_t)tile_sum[i / kScanTile];
-}
-
-__global__ __launch_bounds__(256) void fill_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                                                   int64_t E, int64_t N, const int64_t *__restrict__ rowptr,
-                                                   unsigned long long *__restrict__ cursor, int32_t *__restrict__ col)
-{
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    __shared__ unsigned long long cursor[kMaxBuckets];
+    for (int b = threadIdx.x; b < buckets; b += blockDim.x)
+        cursor[b] = bucket_base[b] + offsets[(int64_t)blockIdx.x * buckets + b];
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * slice_edges;
+    const int64_t hi = lo + slice_edges < E ? lo + slice_edges : E;
+    for (int64_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
         const int64_t s = src[e], d = dst[e];
         if ((uint64_t)s >= (uint64_t)N || (uint64_t)d >= (uint64_t)N) continue;
-        const unsigned long long pos = atomicAdd(&cursor[d], 1ULL);
-        col[rowptr[d] + (int64_t)pos] = (int32_t)s;
+        const unsigned long long pos = atomicAdd(&cursor[d >> shift], 1ULL);
+        staged[pos] = make_int2((int)s, (int)d);
     }
 }
 
-inline int64_t csr_tiles(int64_t N) { return (N + kScanTile - 1) / kScanTile; }
-inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-inline int csr_grid(int64_t items)
+// one block per bucket
+__global__ __launch_bounds__(kFinishThreads) void bucket_finish_kernel(const int2 *__restrict__ staged,
+                                                                       const unsigned long long *__restrict__ bucket_base,
+                                                                       int buckets, int nodes_per_bucket, int64_t N,
+                                                                       int64_t *__restrict__ rowptr, int32_t *__restrict__ col)
 {
-    int64_t g = (items + 255) / 256;
-    if (g < 1) g = 1;
-    if (g > 256 * 16) g = 256 * 16;
-    return (int)g;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *cnt = smem;                       // [NB] counts, then cursors
+    uint32_t *excl = smem + nodes_per_bucket;   // [NB] exclusive offsets
+    __shared__ uint32_t wave_tot[kFinishThreads / kWave];
+    const int b = blockIdx.x;
+    const int64_t node0 = (int64_t)b * nodes_per_bucket;
+    const unsigned long long seg_lo = bucket_base[b];
+    const unsigned long long seg_hi = (b + 1 < buckets) ? bucket_base[b + 1] : (unsigned long long)rowptr[N];
+    for (int i = threadIdx.x; i < nodes_per_bucket; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    for (unsigned long long e = seg_lo + threadIdx.x; e < seg_hi; e += blockDim.x)
+        atomicAdd(&cnt[staged[e].y - (int)node0], 1u);
+    __syncthreads();
+    // exclusive scan of cnt[0..NB): each thread owns a contiguous run
+    const int per = nodes_per_bucket / kFinishThreads;  // NB is a multiple of 1024
+    const int base = threadIdx.x * per;
+    uint32_t run = 0;
+    for (int k = 0; k < per; ++k) run += cnt[base + k];
+    uint32_t inc = run;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == kWave - 1) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int w = 0; w < wv; ++w) pre += wave_tot[w];
+    uint32_t ex = pre + inc - run;
+    for (int k = 0; k < per; ++k) {
+        const uint32_t c = cnt[base + k];
+        excl[base + k] = ex;
+        if (node0 + base + k < N) rowptr[node0 + base + k] = (int64_t)(seg_lo + ex);
+        ex += c;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nodes_per_bucket; i += blockDim.x) cnt[i] = excl[i];
+    __syncthreads();
+    for (unsigned long long e = seg_lo + threadIdx.x; e < seg_hi; e += blockDim.x) {
+        const int2 sd = staged[e];
+        const uint32_t pos = atomicAdd(&cnt[sd.y - (int)node0], 1u);
+        col[seg_lo + pos] = sd.x;
+    }
 }
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace ss
 
-// workspace layout: [deg/cursor: N u64][tile sums: tiles u64]
+// workspace layout: [count matrix: slice_blocks*buckets u32][bucket totals/bases: buckets+1 u64][staged edges: E int2]
 extern "C" size_t ss_csr_workspace_bytes(int64_t N, int64_t E)
 {
-    (void)E;
-    if (N < 0) return 0;
-    return ss::align256((size_t)(N + 1) * 8) + ss::align256((size_t)(ss::csr_tiles(N) + 1) * 8);
+    ss::CsrPlan p;
+    if (N < 0 || E < 0 || !ss::make_plan(N, E, p)) return 0;
+    return ss::align256((size_t)p.slice_blocks * p.buckets * 4) + ss::align256((size_t)(p.buckets + 1) * 8) +
+           ss::align256((size_t)(E > 0 ? E : 1) * 8);
 }
 
 extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
-                            int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_)
+                            int64_t *n_self_loops_out, int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_)
 {
     using namespace ss;
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || !rowptr) return SS_ERR_INVALID_ARG;
     if (E > 0 && (!src || !dst || !col)) return SS_ERR_INVALID_ARG;
+    CsrPlan p;
+    if (!make_plan(N, E, p)) return SS_ERR_UNSUPPORTED;  // N > 64 M nodes
     if (!workspace || workspace_bytes < ss_csr_workspace_bytes(N, E)) return SS_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
-    auto *deg = reinterpret_cast<unsigned long long *>(workspace);
-    auto *tile_sum = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace) + align256((size_t)(N + 1) * 8));
-    const int64_t tiles = csr_tiles(N);
-    if (hipMemsetAsync(deg, 0, (size_t)(N + 1) * 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
-    if (N == 0) {
-        if (hipMemsetAsync(rowptr, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
+    char *ws = reinterpret_cast<char *>(workspace);
+    auto *counts = reinterpret_cast<uint32_t *>(ws);
+    ws += align256((size_t)p.slice_blocks * p.buckets * 4);
+    auto *bucket_total = reinterpret_cast<unsigned long long *>(ws);
+    ws += align256((size_t)(p.buckets + 1) * 8);
+    auto *staged = reinterpret_cast<int2 *>(ws);
+
+    if (n_self_loops_out && hipMemsetAsync(n_self_loops_out, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
+    if (N == 0 || E == 0) {
+        if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
         return SS_OK;
     }
-    if (E > 0) {
-        hipLaunchKernelGGL(degree_kernel, dim3(csr_grid(E)), dim3(256), 0, stream, src, dst, E, N, deg, err_flag);
-        SS_LAUNCH_CHECK();
+    unsigned long long *n_self = reinterpret_cast<unsigned long long *>(n_self_loops_out);
+    unsigned long long *n_self_scratch = bucket_total + p.buckets;  // spare slot when the caller does not want it
+    if (!n_self) {
+        n_self = n_self_scratch;
+        if (hipMemsetAsync(n_self, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3((unsigned)tiles), dim3(kScanBlock), 0, stream, deg, N, rowptr, tile_sum);
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(p.slice_blocks), dim3(kCsrThreads), 0, stream, src, dst, E, N, p.shift, p.buckets,
+                       p.slice_edges, counts, n_self, err_flag);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kScanBlock), 0, stream, tile_sum, tiles, rowptr, N);
+    const int waves_per_block = kCsrThreads / kWave;
+    hipLaunchKernelGGL(bucket_offsets_kernel, dim3((p.buckets + waves_per_block - 1) / waves_per_block), dim3(kCsrThreads), 0, stream,
+                       counts, p.slice_blocks, p.buckets, bucket_total);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(add_tile_offsets_kernel, dim3(csr_grid(N)), dim3(256), 0, stream, rowptr, N, tile_sum);
+    hipLaunchKernelGGL(bucket_bases_kernel, dim3(1), dim3(kCsrThreads), 0, stream, bucket_total, p.buckets, rowptr, N);
     SS_LAUNCH_CHECK();
-    if (E > 0) {
-        if (hipMemsetAsync(deg, 0, (size_t)N * 8, stream) != hipSuccess) return SS_ERR_LAUNCH;  // reuse as cursors
-        hipLaunchKernelGGL(fill_kernel, dim3(csr_grid(E)), dim3(256), 0, stream, src, dst, E, N, rowptr, deg, col);
-        SS_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(p.slice_blocks), dim3(kCsrThreads), 0, stream, src, dst, E, N, p.shift, p.buckets,
+                       p.slice_edges, counts, bucket_total, staged);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bucket_finish_kernel, dim3(p.buckets), dim3(kFinishThreads), (size_t)p.nodes_per_bucket * 8, stream, staged,
+                       bucket_total, p.buckets, p.nodes_per_bucket, N, rowptr, col);
+    SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -33,7 +33,7 @@ __host__ __device__ constexpr int pow2_ceil(int x)
 // TP / TM > 0: compile-time row sizes (fast path); 0: run-time.
 template <int TP, int TM>
 __global__ __launch_bounds__(256) void propagate_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                        int64_t N, int64_t n_self,
+                                                        int64_t N, int64_t n_self_arg, const int64_t *__restrict__ n_self_dev,
                                                         const uint32_t *__restrict__ mh_in, uint32_t *__restrict__ mh_out, int P_rt,
                                                         const uint8_t *__restrict__ hll_in, uint8_t *__restrict__ hll_out, int M_rt,
                                                         float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm)
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(const int64_t *__restric
 
     const int64_t rb = rowptr[i];
     const int deg = (int)(rowptr[i + 1] - rb);
+    const int64_t n_self = n_self_dev ? *n_self_dev : n_self_arg;
     const int self = i < n_self ? 1 : 0;
     const int total = deg + self;
     const int32_t *nb = col + rb;
@@ -127,14 +128,15 @@ __global__ __launch_bounds__(256) void propagate_kernel(const int64_t *__restric
 }
 
 template <int TP, int TM>
-int launch_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self, const uint32_t *mh_in,
+int launch_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self, const int64_t *n_self_dev,
+                     const uint32_t *mh_in,
                      uint32_t *mh_out, int P, const uint8_t *hll_in, uint8_t *hll_out, int M, float *cards_out,
                      int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
 {
     const int rows_per_block = 256 / kWave;
     const int64_t blocks = (N + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL((propagate_kernel<TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, N, n_self, mh_in,
-                       mh_out, P, hll_in, hll_out, M, cards_out, cards_stride, prm);
+    hipLaunchKernelGGL((propagate_kernel<TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, N, n_self, n_self_dev,
+                       mh_in, mh_out, P, hll_in, hll_out, M, cards_out, cards_stride, prm);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -142,7 +144,7 @@ int launch_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64
 }  // namespace ss
 
 extern "C" int ss_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
-                            const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
+                            const int64_t *n_self_loops_dev, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
                             const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
                             float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream)
 {
@@ -164,8 +166,8 @@ extern "C" int ss_propagate(const int64_t *rowptr, const int32_t *col, int64_t N
     }
     const bool fast = (!mh_out || P == 128) && (!hll_out || M == 256);
     if (fast)
-        return launch_propagate<128, 256>(rowptr, col, N, n_self_loops, mh_in, mh_out, 128, hll_in, hll_out, 256, cards_out,
+        return launch_propagate<128, 256>(rowptr, col, N, n_self_loops, n_self_loops_dev, mh_in, mh_out, 128, hll_in, hll_out, 256, cards_out,
                                           cards_stride, p0, (hipStream_t)stream);
-    return launch_propagate<0, 0>(rowptr, col, N, n_self_loops, mh_in, mh_out, P, hll_in, hll_out, M, cards_out, cards_stride, p0,
+    return launch_propagate<0, 0>(rowptr, col, N, n_self_loops, n_self_loops_dev, mh_in, mh_out, P, hll_in, hll_out, M, cards_out, cards_stride, p0,
                                   (hipStream_t)stream);
 }

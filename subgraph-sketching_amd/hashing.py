@@ -214,14 +214,18 @@ def _packed_hll_of(t, device):
 # CSR cache
 # ------------------------------------------------------------------------------------------------
 class CsrGraph(object):
-    """destination-grouped adjacency resident on the device"""
+    """destination-grouped adjacency resident on the device.  `n_self_dev` (device int64[1]) holds
+    max(edge_index) + 1 as computed by ss_csr_build; `use_inferred_self_loops` says whether the propagation adds
+    those implicit self loops (build_hash_tables) or none (hll_prop / minhash_prop get them explicitly)."""
 
-    def __init__(self, rowptr, col, num_nodes, n_self_loops):
-        self.rowptr, self.col, self.num_nodes, self.n_self_loops = rowptr, col, num_nodes, n_self_loops
+    def __init__(self, rowptr, col, num_nodes, n_self_dev, err):
+        self.rowptr, self.col, self.num_nodes, self.n_self_dev, self.err = rowptr, col, num_nodes, n_self_dev, err
+        self.use_inferred_self_loops = False
 
 
 def build_csr(edge_index, num_nodes, device, check=True):
-    """CSR-by-destination of edge_index [2, E] (flow source -> target, reference hashing.py:34,44)"""
+    """CSR-by-destination of edge_index [2, E] (flow source -> target, reference hashing.py:34,44).
+    check=True synchronises once to raise IndexError for endpoints outside [0, num_nodes)."""
     lib = _native.lib()
     ei = edge_index.to(device=device, dtype=torch.int64)
     if ei.dim() != 2 or ei.size(0) != 2:
@@ -230,15 +234,18 @@ def build_csr(edge_index, num_nodes, device, check=True):
     E = src.numel()
     rowptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=device)
     col = torch.empty(max(E, 1), dtype=torch.int32, device=device)
-    err = torch.zeros(1, dtype=torch.int32, device=device)
+    flags = torch.zeros(2, dtype=torch.int64, device=device)  # [0] = n_self (written by the kernel), [1] = error flag
+    n_self_dev, err = flags[0:1], flags[1:2].view(torch.int32)[0:1]
     ws_bytes = lib.ss_csr_workspace_bytes(num_nodes, E)
-    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+    if ws_bytes == 0:
+        raise NotImplementedError(f'graphs with {num_nodes} nodes are not supported by the CSR builder')
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
     with _Span('csr_build', device):
-        _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(err), _ptr(ws),
-                                       ws_bytes, _stream(device)), 'ss_csr_build')
+        _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(n_self_dev), _ptr(err),
+                                       _ptr(ws), ws_bytes, _stream(device)), 'ss_csr_build')
     if check and int(err.item()):
         raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
-    return CsrGraph(rowptr, col, num_nodes, 0)
+    return CsrGraph(rowptr, col, num_nodes, n_self_dev, err)
 
 
 class _CsrCache(object):
@@ -254,7 +261,7 @@ class _CsrCache(object):
         key = (num_nodes, tuple(edge_index.shape), str(device))
         if self._ref is not None and self._ref() is edge_index and self._version == edge_index._version and self._key == key:
             return self._csr
-        csr = build_csr(edge_index, num_nodes, device)
+        csr = build_csr(edge_index, num_nodes, device, check=True)
         self._ref, self._version, self._key, self._csr = weakref.ref(edge_index), edge_index._version, key, csr
         return csr
 
@@ -270,8 +277,9 @@ def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, param
     P = mh_in.size(1) if mh_in is not None else 0
     M = hll_in.size(1) if hll_in is not None else 0
     prm = byref(params.struct) if params is not None else None
+    n_self_dev = csr.n_self_dev if csr.use_inferred_self_loops else None
     with _Span('propagate', device):
-        _native.check(_native.lib().ss_propagate(_ptr(csr.rowptr), _ptr(csr.col), N, csr.n_self_loops, _ptr(mh_in),
+        _native.check(_native.lib().ss_propagate(_ptr(csr.rowptr), _ptr(csr.col), N, 0, _ptr(n_self_dev), _ptr(mh_in),
                                                  _ptr(mh_out), P, _ptr(hll_in), _ptr(hll_out), M, _ptr(cards_out),
                                                  cards_stride, prm, _stream(device)), 'ss_propagate')
     return mh_out, hll_out
@@ -452,12 +460,10 @@ class ElphHashes(object):
         home = edge_index.device
         device = _compute_device(edge_index)
         params = self._params(device)
-        # add_self_loops without num_nodes (reference :148): loops for i < max(edge_index) + 1 only
-        n_self = int(edge_index.max()) + 1 if edge_index.numel() > 0 else 0
-        if n_self > num_nodes:
-            raise IndexError(f'edge_index refers to node {n_self - 1} but num_nodes is {num_nodes}')
-        csr = build_csr(edge_index, num_nodes, device)
-        csr.n_self_loops = n_self
+        # add_self_loops without num_nodes (reference :148): loops for i < max(edge_index) + 1 only; the count is
+        # produced on the device by ss_csr_build and read by the propagation kernel -- no host round trip
+        csr = build_csr(edge_index, num_nodes, device, check=self.strict_bounds)
+        csr.use_inferred_self_loops = True
         cards = torch.zeros((num_nodes, self.max_hops), dtype=torch.float32, device=device)
         table = SketchTable()
         mh = self._init_minhash_u32(num_nodes, device)
