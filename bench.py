@@ -157,6 +157,7 @@ def main():
     prop_ms, prop_n = timer.mean_ms('propagate')
     pair_ms, pair_n = timer.mean_ms('pair_features')
     csr_ms, _ = timer.mean_ms('csr_build')
+    first_ms, _ = timer.mean_ms('first_hop')
     e_prime = 2 * E_UND + N_NODES
     prop_bytes = (e_prime + N_NODES) * ROW_BYTES + 4 * e_prime + 8 * (N_NODES + 1) + 4 * N_NODES
     pair_bytes = BATCH * (2 * H * ROW_BYTES + 16 + 8 * H + 4 * H * (H + 2))
@@ -181,7 +182,7 @@ def main():
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': prop_bytes / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if prop_ms else None, 'traffic': traffic,
                      'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n},
-        'kernels': {'propagate_ms_per_launch': prop_ms, 'pair_features_ms_per_launch': pair_ms, 'csr_build_ms': csr_ms,
+        'kernels': {'propagate_ms_per_launch': prop_ms, 'first_hop_ms_per_launch': first_ms, 'pair_features_ms_per_launch': pair_ms, 'csr_build_ms': csr_ms,
                     'pair_features_algorithmic_bytes': pair_bytes,
                     'pair_features_GBps': pair_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms else None,
                     'pair_features_frac_of_hbm_peak': pair_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pair_ms else None,

@@ -98,6 +98,16 @@ int ss_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n
                  const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
                  float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream);
 
+/* Hop 1 straight from node ids: equivalent to ss_minhash_init + ss_hll_init + one ss_propagate
+ * (hashing.py:118-137, 28-45 at k = 1, 163) but the hop-0 rows -- pure functions of the node id -- are
+ * recomputed in registers instead of being written to and re-read from HBM.  a / b: device uint64[P].
+ * Returns SS_ERR_UNSUPPORTED when (P, p) is outside the fused kernel's shape (p == 8, P % 64 == 0, P <= 256):
+ * the caller then uses the three-call sequence. */
+int ss_first_hop(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
+                 const int64_t *n_self_loops_dev, const uint64_t *a, const uint64_t *b, int32_t P,
+                 uint32_t *mh_out, int32_t p, uint8_t *hll_out, float *cards_out, int64_t cards_stride,
+                 const ss_hll_params *prm, void *stream);
+
 /* HLL++ cardinality of n register rows.  Replaces ElphHashes.hll_count (+ _linearcounting,
  * _estimate_bias, _refine_hll_count_estimate; hashing.py:194-232).  regs: device uint8[n, m];
  * out: device fp32, element i written to out[i*out_stride]. */

@@ -34,6 +34,8 @@ SIGNATURES = {
                                c_size_t, c_void_p]),
     'ss_propagate': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p]),
+    'ss_first_hop': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
+                               c_void_p, c_void_p, c_int64, POINTER(HllParams), c_void_p]),
     'ss_hll_count': (c_int32, [c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int64, c_void_p]),
     'ss_estimate_bias': (c_int32, [c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int32, c_void_p]),
     'ss_pair_features': (c_int32, [c_void_p, c_int64, c_int64, c_int32, POINTER(c_void_p), c_int32, POINTER(c_void_p),

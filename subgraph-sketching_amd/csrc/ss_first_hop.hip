@@ -1,0 +1,154 @@
+// ss_first_hop.hip -- hop 1 computed straight from node ids (fused hop-0 init + first propagation).
+//
+// Hop-0 sketches are pure functions of the node id (reference hashing.py:118-137): row t of the MinHash
+// table is ((a_j * hv_t + b_j) mod 2^64 mod (2^61-1)) & 0xFFFFFFFF, row t of the HLL table has the single
+// register (hv_t & (m-1)) = rank(hv_t).  Reading them back from HBM for the first propagation
+// (hashing.py:160-161 at k = 1) costs (E' + N) * 768 B; recomputing them in registers costs ~25 VALU
+// issue slots per (neighbour, lane) and no table traffic at all -- the kernel reads only the CSR and
+// writes the hop-1 rows.  Results are identical to ss_minhash_init + ss_hll_init + ss_propagate.
+//
+// Mapping: one wavefront per destination row.  Lane l owns permutations l, l+64, .. (P/64 of them) and
+// HLL registers 4l..4l+3 (M = 256).  Neighbour ids are fetched 64 at a time (one coalesced load), every
+// lane hashes ITS neighbour (64 hashes in parallel), then the wave walks the batch with v_readlane:
+// the neighbour's hash is wave-uniform (SGPR pair), each lane evaluates its own permutations on it.
+#include "ss_common.hpp"
+
+namespace ss {
+
+__device__ __forceinline__ uint32_t permuted_hash(uint64_t a, uint64_t b, uint64_t hv)
+{
+    return (uint32_t)mod_mersenne61(a * hv + b);
+}
+
+template <int PPL /* permutations per lane = P / 64 */>
+__global__ __launch_bounds__(256) void first_hop_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t N,
+                                                        int64_t n_self_arg, const int64_t *__restrict__ n_self_dev,
+                                                        const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
+                                                        uint32_t *__restrict__ mh_out, int p, uint8_t *__restrict__ hll_out,
+                                                        float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm)
+{
+    __shared__ EstimatorLds lds;
+    __shared__ uint32_t hll_rows[256 / kWave][256];  // one u32 per HLL register and wave (LDS scatter-max target)
+    const bool want_cards = cards_out != nullptr;
+    EstimatorTables est;
+    if (want_cards) est = stage_tables(lds, prm);
+
+    constexpr int P = PPL * kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    // wave-uniform row id (readfirstlane makes the uniformity visible to the compiler: scalar loads, scalar loop control)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + wave;
+    if (i >= N) return;
+
+    uint64_t a[PPL], b[PPL];
+    uint32_t acc[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        a[q] = pa[lane + kWave * q];
+        b[q] = pb[lane + kWave * q];
+        acc[q] = 0xFFFFFFFFu;
+    }
+    uint32_t *my_row = hll_rows[wave];
+    *reinterpret_cast<u32x4 *>(my_row + 4 * lane) = u32x4{0u, 0u, 0u, 0u};
+
+    const int64_t rb = rowptr[i];
+    const int deg = (int)(rowptr[i + 1] - rb);
+    const int64_t n_self = n_self_dev ? *n_self_dev : n_self_arg;
+    const int total = deg + (i < n_self ? 1 : 0);
+    const int32_t *nb = col + rb;
+
+    for (int base = 0; base < total; base += kWave) {
+        const int t = base + lane;
+        const int64_t nid = t < deg ? (int64_t)nb[t] : i;      // t == deg is the implicit self loop; t > deg unused
+        const uint64_t hv = hash_u64((uint64_t)(nid + 1));
+        const uint32_t hv_lo = (uint32_t)hv, hv_hi = (uint32_t)(hv >> 32);
+        // HLL (hashing.py:126-137): every lane scatters ITS neighbour's single register into the wave's LDS row
+        if (t < total) {
+            const uint64_t bits = hv >> p;
+            const int bl = bits ? 64 - __builtin_clzll(bits) : 0;
+            atomicMax(&my_row[hv_lo & 255u], (uint32_t)((64 - p) - bl + 1));
+        }
+        // MinHash: walk the batch; the neighbour's hash is wave-uniform, each lane evaluates its own permutations
+        const int cnt = total - base < kWave ? total - base : kWave;
+        int k = 0;
+        for (; k + 1 < cnt; k += 2) {
+            const uint64_t h0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv_hi, k) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k);
+            const uint64_t h1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv_hi, k + 1) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k + 1);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const uint32_t v0 = permuted_hash(a[q], b[q], h0);
+                const uint32_t v1 = permuted_hash(a[q], b[q], h1);
+                const uint32_t v = v0 < v1 ? v0 : v1;
+                acc[q] = v < acc[q] ? v : acc[q];
+            }
+        }
+        if (k < cnt) {
+            const uint64_t h0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv_hi, k) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const uint32_t v = permuted_hash(a[q], b[q], h0);
+                acc[q] = v < acc[q] ? v : acc[q];
+            }
+        }
+    }
+    if (total == 0) {
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) acc[q] = 0u;  // no in-edge, no self loop: all-zero row (PyG default)
+    }
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = acc[q];
+    // the wave's LDS row is only touched by this wave: a wave-level fence orders the atomics before the read
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const u32x4 r4 = *reinterpret_cast<const u32x4 *>(my_row + 4 * lane);
+    const uint32_t regs = r4.x | (r4.y << 8) | (r4.z << 16) | (r4.w << 24);  // HLL registers 4*lane .. 4*lane+3
+    *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
+
+    if (want_cards) {
+        int zeros = 0;
+        float hsum = 0.0f;
+        hll_dword_stats(regs, zeros, hsum);
+        for (int off = 1; off < kWave; off <<= 1) {
+            zeros += __shfl_xor(zeros, off);
+            hsum += __shfl_xor(hsum, off);
+        }
+        if (lane == 0) cards_out[i * cards_stride] = hll_estimate(est, zeros, hsum);
+    }
+}
+
+}  // namespace ss
+
+extern "C" int ss_first_hop(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
+                            const int64_t *n_self_loops_dev, const uint64_t *a, const uint64_t *b, int32_t P,
+                            uint32_t *mh_out, int32_t p, uint8_t *hll_out, float *cards_out, int64_t cards_stride,
+                            const ss_hll_params *prm, void *stream)
+{
+    using namespace ss;
+    if (N < 0 || !rowptr) return SS_ERR_INVALID_ARG;
+    if (p != 8 || P <= 0 || P % kWave || P > 256) return SS_ERR_UNSUPPORTED;  // caller falls back to init + propagate
+    if (N == 0) return SS_OK;
+    if (!a || !b || !mh_out || !hll_out || N >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
+    ss_hll_params p0 = {};
+    if (cards_out) {
+        const int rc = check_params(prm);
+        if (rc != SS_OK) return rc;
+        if (prm->p != p) return SS_ERR_INVALID_ARG;
+        p0 = *prm;
+    }
+    const int64_t blocks = (N + 3) / 4;
+    hipStream_t s = (hipStream_t)stream;
+#define SS_LAUNCH_FIRST_HOP(PPL)                                                                                              \
+    hipLaunchKernelGGL((first_hop_kernel<PPL>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, N, n_self_loops,         \
+                       n_self_loops_dev, a, b, mh_out, (int)p, hll_out, cards_out, cards_stride, p0)
+    switch (P / kWave) {
+        case 1: SS_LAUNCH_FIRST_HOP(1); break;
+        case 2: SS_LAUNCH_FIRST_HOP(2); break;
+        case 3: SS_LAUNCH_FIRST_HOP(3); break;
+        default: SS_LAUNCH_FIRST_HOP(4); break;
+    }
+#undef SS_LAUNCH_FIRST_HOP
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void propagate_kernel(const int64_t *__restric
     const int P = TP ? TP : P_rt;
     const int M = TM ? TM : M_rt;
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    // wave-uniform row id (readfirstlane makes the uniformity visible to the compiler: scalar loads, scalar loop control)
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     if (i >= N) return;
 
     const int64_t rb = rowptr[i];

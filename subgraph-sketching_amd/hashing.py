@@ -122,11 +122,27 @@ class HopSketch(dict):
     left them on: where edge_index lived)."""
     _KEYS = ('hll', 'minhash')
 
-    def __init__(self, mh_u32, hll_u8, home):
+    def __init__(self, mh_u32, hll_u8, home, make_packed=None):
         super().__init__({'hll': None, 'minhash': None})
-        self.mh_u32 = mh_u32
-        self.hll_u8 = hll_u8
+        self._mh_u32 = mh_u32
+        self._hll_u8 = hll_u8
+        self._make_packed = make_packed  # deferred producer of (mh_u32, hll_u8): hop 0 is only built if somebody reads it
         self.home = home
+
+    def _ensure_packed(self):
+        if self._mh_u32 is None and self._make_packed is not None:
+            self._mh_u32, self._hll_u8 = self._make_packed()
+            self._make_packed = None
+
+    @property
+    def mh_u32(self):
+        self._ensure_packed()
+        return self._mh_u32
+
+    @property
+    def hll_u8(self):
+        self._ensure_packed()
+        return self._hll_u8
 
     def _materialise(self, key):
         val = dict.__getitem__(self, key)
@@ -363,6 +379,7 @@ class ElphHashes(object):
         self.hll_prop = HllPropagation(self._csr_cache)
         self._dev_params = {}
         self._dev_perms = {}
+        self.fuse_first_hop = True  # compute hop 1 straight from node ids when the fused kernel supports (num_perm, p)
         self.strict_bounds = True  # raise IndexError for out-of-range node ids (costs one 4-byte D2H per call)
 
     # no device handles in pickled state (SURVEY.md section 8(b) threading row)
@@ -464,16 +481,42 @@ class ElphHashes(object):
         # produced on the device by ss_csr_build and read by the propagation kernel -- no host round trip
         csr = build_csr(edge_index, num_nodes, device, check=self.strict_bounds)
         csr.use_inferred_self_loops = True
-        cards = torch.zeros((num_nodes, self.max_hops), dtype=torch.float32, device=device)
+        cards = torch.empty((num_nodes, self.max_hops), dtype=torch.float32, device=device)
         table = SketchTable()
-        mh = self._init_minhash_u32(num_nodes, device)
-        hll = self._init_hll_u8(num_nodes, device)
-        table[0] = HopSketch(mh, hll, home)
-        for k in range(1, self.max_hops + 1):
+        mh, hll = self._first_hop(csr, num_nodes, device, cards, params)
+        if mh is not None:
+            # hop 1 was computed straight from node ids; the hop-0 tables (pure functions of the node id, never read
+            # by get_subgraph_features) are produced only if a caller actually looks at them
+            table[0] = HopSketch(None, None, home, make_packed=lambda n=num_nodes, d=device: (self._init_minhash_u32(n, d),
+                                                                                            self._init_hll_u8(n, d)))
+            first = 2
+            table[1] = HopSketch(mh, hll, home)
+        else:
+            mh = self._init_minhash_u32(num_nodes, device)
+            hll = self._init_hll_u8(num_nodes, device)
+            table[0] = HopSketch(mh, hll, home)
+            first = 1
+        for k in range(first, self.max_hops + 1):
             logger.info(f"Calculating hop {k} hashes")
             mh, hll = _propagate(csr, mh, hll, device, cards_out=cards[:, k - 1], cards_stride=self.max_hops, params=params)
             table[k] = HopSketch(mh, hll, home)
         return table, (cards if home == device else cards.to(home))
+
+    def _first_hop(self, csr, num_nodes, device, cards, params):
+        """fused hop-0 + hop-1 (ss_first_hop); returns (None, None) when the kernel has no variant for (P, p)"""
+        if not self.fuse_first_hop:
+            return None, None
+        ab = self._perms(device)
+        mh = torch.empty((num_nodes, self.num_perm), dtype=torch.int32, device=device)
+        hll = torch.empty((num_nodes, self.m), dtype=torch.uint8, device=device)
+        with _Span('first_hop', device):
+            rc = _native.lib().ss_first_hop(_ptr(csr.rowptr), _ptr(csr.col), num_nodes, 0, _ptr(csr.n_self_dev), _ptr(ab[0]),
+                                            _ptr(ab[1]), self.num_perm, _ptr(mh), self.p, _ptr(hll), _ptr(cards),
+                                            self.max_hops, byref(params.struct), _stream(device))
+        if rc == -4:  # SS_ERR_UNSUPPORTED: no fused variant for this (num_perm, p)
+            return None, None
+        _native.check(rc, 'ss_first_hop')
+        return mh, hll
 
     # ---- query ---------------------------------------------------------------------------------------
     def _resolve_tables(self, hash_table, device):
