@@ -32,14 +32,29 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# BASELINE.json configs as synthetic shapes.  The default -- and the only one the driver's
+# plain `python bench.py` measures -- is configs[1] (collab).  The others are selectable for profiling.
+CONFIGS = {
+    'collab': dict(n=235868, e_und=1179052, h=2, batch=65536),      # configs[1] / [2]
+    'cora': dict(n=2485, e_und=3550, h=2, batch=1024),              # configs[0] shape (plumbing)
+    'ppa': dict(n=576289, e_und=21231931, h=2, batch=131072),       # configs[3]
+    'citation2': dict(n=2927963, e_und=30387995, h=3, batch=261424),  # configs[4]
+}
 N_NODES, E_UND, H, P, HLL_P, BATCH = 235868, 1179052, 2, 128, 8, 65536
 ROW_BYTES = 4 * P + (1 << HLL_P)
 HBM_PEAK_GBS = 8000.0
+GRAPH_KIND, PL_ALPHA = 'uniform', 0.5
 
 
 def synthetic_graph(seed=1):
     rng = np.random.RandomState(seed)
-    e = rng.randint(0, N_NODES, size=(2, E_UND)).astype(np.int64)
+    if GRAPH_KIND == 'uniform':
+        e = rng.randint(0, N_NODES, size=(2, E_UND)).astype(np.int64)
+    else:  # power-law endpoint weights w_i ~ (i+1)^-alpha (Chung-Lu style): exercises hub rows
+        w = np.arange(1, N_NODES + 1, dtype=np.float64) ** -PL_ALPHA
+        cdf = np.cumsum(w / w.sum())
+        e = np.stack([np.searchsorted(cdf, rng.random_sample(E_UND)), rng.randint(0, N_NODES, size=E_UND)]).astype(np.int64)
+        e = np.minimum(e, N_NODES - 1)
     return np.concatenate([e, e[::-1]], axis=1)
 
 
@@ -99,8 +114,15 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config', default='collab', choices=sorted(CONFIGS), help='synthetic shape (default: BASELINE configs[1])')
+    ap.add_argument('--graph', default='uniform', choices=['uniform', 'powerlaw'])
+    ap.add_argument('--alpha', type=float, default=0.5, help='power-law exponent of the endpoint weights')
     a = ap.parse_args()
+    global N_NODES, E_UND, H, BATCH, GRAPH_KIND, PL_ALPHA
+    cfg = CONFIGS[a.config]
+    N_NODES, E_UND, H, BATCH, GRAPH_KIND, PL_ALPHA = cfg['n'], cfg['e_und'], cfg['h'], cfg['batch'], a.graph, a.alpha
 
+    launched = 'RANK' in os.environ  # under torchrun (also with one rank, so the RCCL path can be smoke-tested)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -108,7 +130,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if launched:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
     assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {a.gpus}'
@@ -123,18 +145,18 @@ def main():
     links_np = synthetic_links(2 + rank)
     ei = torch.from_numpy(ei_np).to(dev)
     links = torch.from_numpy(links_np).to(dev)
-    gathered = torch.empty((world * BATCH, H * (H + 2)), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * BATCH, H * (H + 2)), dtype=torch.float32, device=dev) if launched else None
 
     def step():
         table, cards = eh.build_hash_tables(N_NODES, ei)
         f = eh.get_subgraph_features(links, table, cards)
-        if world > 1:
+        if launched:
             dist.all_gather_into_tensor(gathered, f)
         return f
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -149,7 +171,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     hashing.KERNEL_TIMER = None
-    if world > 1:
+    if launched:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -172,13 +194,13 @@ def main():
         'value': world * BATCH * a.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'u32/u8 sketches, f32 estimator', 'data': 'synthetic',
-        'config': {'workload': 'ogbl-collab-like synthetic graph (BASELINE configs[1]), BUDDY/ELPH hot path: step = '
-                               'build_hash_tables + get_subgraph_features, nothing cached across steps',
+        'config': {'workload': f'ogbl-{a.config}-like synthetic {a.graph} graph' + (' (BASELINE configs[1])' if a.config == 'collab' else '') +
+                               ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps',
                    'num_nodes': N_NODES, 'directed_edges': 2 * E_UND, 'max_hash_hops': H, 'minhash_num_perm': P, 'hll_p': HLL_P,
                    'pairs_per_step_per_gpu': BATCH, 'global_pairs_per_step': world * BATCH,
                    'parallelism': f'edge-batch sharded x{world}, sketch table replicated, all_gather of features',
                    'hll_tables': eh.hll_tables.provenance},
-        'roofline': {'kernel': 'ss::propagate_kernel<128,256>', 'bound': 'hbm', 'achieved': prop_bytes / (prop_ms * 1e-3) / 1e9 if prop_ms else None,
+        'roofline': {'kernel': 'ss::propagate_kernel<128,256>' + ('' if H > 1 else ' (not launched at h=1)'), 'bound': 'hbm', 'achieved': prop_bytes / (prop_ms * 1e-3) / 1e9 if prop_ms else None,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': prop_bytes / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if prop_ms else None, 'traffic': traffic,
                      'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n},
@@ -188,7 +210,7 @@ def main():
                     'pair_features_frac_of_hbm_peak': pair_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pair_ms else None,
                     'query_only_pairs_per_s': BATCH / (pair_ms * 1e-3) if pair_ms else None},
     }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config in ('collab', 'cora'):
         base, ofeat = cpu_baseline(ei_np, links_np)
         out['cpu_baseline'] = base
         diff = float(np.abs(feats.cpu().numpy() - ofeat).max())
@@ -198,7 +220,7 @@ def main():
         out['cpu_baseline'] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

@@ -72,6 +72,20 @@ int ss_minhash_init(uint32_t *out, int64_t first_node, int64_t n, const uint64_t
  * 91-104): one non-zero register per row. */
 int ss_hll_init(uint8_t *out, int64_t first_node, int64_t n, int32_t p, void *stream);
 
+/* Destination-grouped adjacency resident on the device (built by ss_csr_build, consumed by the propagation
+ * kernels).  The struct itself lives on the host and is read at launch. */
+typedef struct ss_csr_graph {
+    const int64_t *rowptr;            /* device int64[N+1]                                                    */
+    const int32_t *col;               /* device int32[E]: source ids grouped by destination                    */
+    int64_t num_nodes;                /* N                                                                     */
+    int64_t n_self_loops;             /* rows i < n_self_loops also receive their own row (implicit self loop)  */
+    const int64_t *n_self_loops_dev;  /* device int64 (nullable): overrides n_self_loops, read by the kernels   */
+    int32_t hub_threshold;            /* rows with more than this many in-edges are "hub rows" ...              */
+    int32_t reserved;
+    const int32_t *hub_rows;          /* ... listed here (device int32[*hub_count], nullable) and processed by  */
+    const int32_t *hub_count;         /* a 16-wave cooperative kernel instead of a single wavefront             */
+} ss_csr_graph;
+
 /* CSR-by-destination of an edge list.  Replaces the message materialisation of
  * torch_geometric MessagePassing.propagate as used by hashing.py:34,44 (flow source -> target).
  *   src/dst: device int64[E] (edge_index[0], edge_index[1]);  rowptr: device int64[N+1];
@@ -79,22 +93,22 @@ int ss_hll_init(uint8_t *out, int64_t first_node, int64_t n, int32_t p, void *st
  *   n_self_loops_out: device int64 (nullable) <- max(edge_index) + 1 (0 for E == 0): the number of self loops
  *   torch_geometric.utils.add_self_loops(edge_index) appends when num_nodes is not given (hashing.py:148), so
  *   the host never has to synchronise on edge_index.max().
+ *   hub_rows / hub_count (device int32[N] / int32, both nullable): rows with more than hub_threshold in-edges.
  *   err_flag: device int32 (nullable), set to 1 if any endpoint is outside [0, N) (such edges are dropped).
  * Workspace: ss_csr_workspace_bytes(N, E) bytes (0 = unsupported size).  No per-edge global atomics: a
  * two-level counting sort (LDS histograms per edge slice -> bucket offsets -> per-bucket LDS sort). */
 size_t ss_csr_workspace_bytes(int64_t N, int64_t E);
 int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
-                 int64_t *n_self_loops_out, int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream);
+                 int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
+                 int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream);
 
 /* One hop of sketch propagation over a CSR: out[i] = min (MinHash) / max (HLL) over the in-neighbours
  * of i, plus row i itself when i < n_self_loops (the implicit self loops of add_self_loops,
  * hashing.py:148); rows with no in-edge and no self loop are all-zero (PyG scatter default).
  * Replaces MinhashPropagation.forward / HllPropagation.forward (hashing.py:28-45) and, when
  * cards_out != NULL, the hll_count of hashing.py:163 (cards_out[i*cards_stride] = hll_count(out row)).
- * Either sketch may be NULL (both in and out).  n_self_loops_dev (device int64, nullable) overrides the
- * scalar n_self_loops when given (the value ss_csr_build produced, read by the kernel itself). */
-int ss_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
-                 const int64_t *n_self_loops_dev, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
+ * Either sketch may be NULL (both in and out). */
+int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
                  const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
                  float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream);
 
@@ -103,8 +117,7 @@ int ss_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n
  * recomputed in registers instead of being written to and re-read from HBM.  a / b: device uint64[P].
  * Returns SS_ERR_UNSUPPORTED when (P, p) is outside the fused kernel's shape (p == 8, P % 64 == 0, P <= 256):
  * the caller then uses the three-call sequence. */
-int ss_first_hop(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
-                 const int64_t *n_self_loops_dev, const uint64_t *a, const uint64_t *b, int32_t P,
+int ss_first_hop(const ss_csr_graph *graph, const uint64_t *a, const uint64_t *b, int32_t P,
                  uint32_t *mh_out, int32_t p, uint8_t *hll_out, float *cards_out, int64_t cards_stride,
                  const ss_hll_params *prm, void *stream);
 
@@ -141,8 +154,7 @@ int ss_unpack_minhash(const uint32_t *in, int64_t *out, int64_t count, void *str
 /* Launch-duration probe for bench.py: records HIP events around `reps` back-to-back launches of the
  * same ss_propagate / ss_pair_features call ON `stream` and returns the mean milliseconds per launch in
  * *ms_out (host pointer).  Synchronises the stream. */
-int ss_time_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
-                      const int64_t *n_self_loops_dev, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
+int ss_time_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
                       const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
                       float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream,
                       int32_t reps, float *ms_out);

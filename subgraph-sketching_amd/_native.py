@@ -23,6 +23,13 @@ class HllParams(ctypes.Structure):
                 ('raw_est', c_void_p), ('bias', c_void_p), ('lc_table', c_void_p)]
 
 
+class CsrGraphStruct(ctypes.Structure):
+    """mirror of `struct ss_csr_graph`"""
+    _fields_ = [('rowptr', c_void_p), ('col', c_void_p), ('num_nodes', c_int64), ('n_self_loops', c_int64),
+                ('n_self_loops_dev', c_void_p), ('hub_threshold', c_int32), ('reserved', c_int32),
+                ('hub_rows', c_void_p), ('hub_count', c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/subgraph_sketch.h
 SIGNATURES = {
     'ss_version': (c_int32, []),
@@ -30,11 +37,11 @@ SIGNATURES = {
     'ss_minhash_init': (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]),
     'ss_hll_init': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'ss_csr_workspace_bytes': (c_size_t, [c_int64, c_int64]),
-    'ss_csr_build': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_size_t, c_void_p]),
-    'ss_propagate': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+    'ss_csr_build': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ss_propagate': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p]),
-    'ss_first_hop': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
+    'ss_first_hop': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p, c_int32,
                                c_void_p, c_void_p, c_int64, POINTER(HllParams), c_void_p]),
     'ss_hll_count': (c_int32, [c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int64, c_void_p]),
     'ss_estimate_bias': (c_int32, [c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int32, c_void_p]),
@@ -43,7 +50,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p]),
     'ss_pack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_unpack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
-    'ss_time_propagate': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+    'ss_time_propagate': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p,
                                     c_void_p, c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int32,
                                     POINTER(c_float)]),
     'ss_time_pair_features': (c_int32, [c_void_p, c_int64, c_int64, c_int32, POINTER(c_void_p), c_int32,

@@ -39,14 +39,13 @@ int time_launches(hipStream_t stream, int reps, float *ms_out, F &&launch)
 }
 }  // namespace
 
-extern "C" int ss_time_propagate(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
-                                 const int64_t *n_self_loops_dev, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
+extern "C" int ss_time_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
                                  const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
                                  float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream,
                                  int32_t reps, float *ms_out)
 {
     return time_launches((hipStream_t)stream, reps, ms_out, [&]() {
-        return ss_propagate(rowptr, col, N, n_self_loops, n_self_loops_dev, mh_in, mh_out, P, hll_in, hll_out, M, cards_out, cards_stride, prm,
+        return ss_propagate(graph, mh_in, mh_out, P, hll_in, hll_out, M, cards_out, cards_stride, prm,
                             stream);
     });
 }

@@ -71,18 +71,31 @@ __device__ __forceinline__ u32x4 min4(u32x4 a, u32x4 b)
     return r;
 }
 
-// 2^-r as fp32 for r in 0..126, built from the exponent field (exact)
-__device__ __forceinline__ float exp2_neg(uint32_t r) { return __uint_as_float((127u - r) << 23); }
+// ---- HLL register statistics (zero count V and harmonic sum S = sum_j 2^-reg_j of hashing.py:221,228) ----------
+// 2^-r in bf16 is the bit pattern 0x3F80 - (r << 7): the registers of a dword are turned into two packed-bf16
+// words (even / odd bytes) with shift-and-subtract, and summed by v_dot2c_f32_bf16 against (1.0, 1.0) -- exact
+// products, fp32 accumulation.  Full-rate VALU costs 4 cycles per wave64 instruction on this part, so the
+// instruction count of this helper (11 per dword instead of ~22 with per-byte extraction) is what matters.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// zero-register count and harmonic sum of the 4 registers of one dword
-__device__ __forceinline__ void hll_dword_stats(uint32_t w, int &zeros, float &sum)
+__device__ __forceinline__ uint32_t regs_even_to_bf16(uint32_t x) { return 0x3F803F80u - ((x << 7) & 0x7F807F80u); }
+__device__ __forceinline__ uint32_t regs_odd_to_bf16(uint32_t x) { return 0x3F803F80u - ((x >> 1) & 0x7F807F80u); }
+
+__device__ __forceinline__ float dot2_ones(uint32_t packed_bf16, float acc)
 {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t r = (w >> (8 * k)) & 0xFFu;
-        zeros += (r == 0u);
-        sum += exp2_neg(r);
-    }
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed_bf16), __builtin_bit_cast(bf16x2, 0x3F803F80u), acc,
+                                           false);
+}
+
+// bit 7 of every byte set iff the byte (a register value <= 127) is non-zero
+__device__ __forceinline__ uint32_t nonzero_byte_flags(uint32_t x) { return (x + 0x7F7F7F7Fu) & 0x80808080u; }
+
+// accumulates the number of NON-zero registers and the harmonic sum of the 4 registers of one dword
+__device__ __forceinline__ void hll_dword_stats(uint32_t w, int &nonzero, float &sum)
+{
+    sum = dot2_ones(regs_even_to_bf16(w), sum);
+    sum = dot2_ones(regs_odd_to_bf16(w), sum);
+    nonzero += __builtin_popcount(nonzero_byte_flags(w));
 }
 
 // ---- DPP reductions inside a 16-lane row: every lane ends with the row total ----------------------
@@ -189,6 +202,22 @@ __device__ __forceinline__ EstimatorTables stage_tables(EstimatorLds &lds, const
     t.alpha_mm = prm.alpha_mm;
     t.five_m = 5.0f * (float)(1 << prm.p);
     return t;
+}
+
+struct GraphArgs {  // device-side view of ss_csr_graph
+    const int64_t *rowptr;
+    const int32_t *col;
+    int64_t N;
+    int64_t n_self;
+    const int64_t *n_self_dev;
+    int hub_threshold;
+    const int32_t *hub_rows;
+    const int32_t *hub_count;
+};
+
+inline GraphArgs to_args(const ss_csr_graph &g)
+{
+    return GraphArgs{g.rowptr, g.col, g.num_nodes, g.n_self_loops, g.n_self_loops_dev, g.hub_threshold, g.hub_rows, g.hub_count};
 }
 
 inline int check_params(const ss_hll_params *prm)

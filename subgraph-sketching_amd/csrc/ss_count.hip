@@ -16,22 +16,22 @@ __global__ __launch_bounds__(256) void hll_count_kernel(const uint8_t *__restric
     const int g = lane / SG, cl = lane % SG;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
     const int64_t row = wave * G + g;
-    int zeros = 0;
+    int nonzero = 0;
     float hsum = 0.0f;
     if (row < n) {
         for (int c = cl; c < CH; c += SG) {
             const u32x4 x = *reinterpret_cast<const u32x4 *>(regs + row * M + 16 * c);
-            hll_dword_stats(x.x, zeros, hsum);
-            hll_dword_stats(x.y, zeros, hsum);
-            hll_dword_stats(x.z, zeros, hsum);
-            hll_dword_stats(x.w, zeros, hsum);
+            hll_dword_stats(x.x, nonzero, hsum);
+            hll_dword_stats(x.y, nonzero, hsum);
+            hll_dword_stats(x.z, nonzero, hsum);
+            hll_dword_stats(x.w, nonzero, hsum);
         }
     }
     for (int off = 1; off < SG; off <<= 1) {
-        zeros += __shfl_xor(zeros, off);
+        nonzero += __shfl_xor(nonzero, off);
         hsum += __shfl_xor(hsum, off);
     }
-    if (row < n && cl == 0) out[row * out_stride] = hll_estimate(est, zeros, hsum);
+    if (row < n && cl == 0) out[row * out_stride] = hll_estimate(est, M - nonzero, hsum);
 }
 
 __global__ __launch_bounds__(256) void estimate_bias_kernel(const float *__restrict__ e, int64_t n, float *__restrict__ out,

@@ -17,13 +17,14 @@
 //                       edges are written as (src, dst) int32 pairs grouped by bucket.
 //   B  bucket_finish  : one block per bucket: LDS histogram over its NB nodes, LDS scan -> rowptr,
 //                       LDS cursors -> col.
+#include <cstdlib>
 #include "ss_common.hpp"
 
 namespace ss {
 
 constexpr int kCsrThreads = 256;
 constexpr int kEdgesPerBlockMin = 4096;   // slice size lower bound (A1 / A4)
-constexpr int kMaxSliceBlocks = 1024;
+constexpr int kMaxSliceBlocks = 4096;
 constexpr int kMaxBuckets = 4096;         // LDS histogram size of A1 / A4
 constexpr int kMinNodesPerBucket = 1024;
 constexpr int kMaxNodesPerBucket = 16384; // LDS of B: 2 * NB * 4 bytes
@@ -40,6 +41,10 @@ struct CsrPlan {
 inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
 {
     int nb = kMinNodesPerBucket, shift = 10;
+    if (const char *env = getenv("SS_CSR_NB_LOG2")) {  // tuning knob (experiments only)
+        const int v = atoi(env);
+        if (v >= 8 && v <= 14) { shift = v; nb = 1 << v; }
+    }
     while ((N + nb - 1) / nb > kMaxBuckets && nb < kMaxNodesPerBucket) { nb <<= 1; ++shift; }
     if ((N + nb - 1) / nb > kMaxBuckets) return false;
     p.shift = shift;
@@ -54,43 +59,37 @@ inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
     return true;
 }
 
-__global__ __launch_bounds__(kCsrThreads) void bucket_count_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                                                                   int64_t E, int64_t N, int shift, int buckets, int64_t slice_edges,
-                                                                   uint32_t *__restrict__ counts /*[blocks][buckets]*/,
-                                                                   unsigned long long *__restrict__ n_self /* max id + 1 */,
-                                                                   int32_t *__restrict__ err)
+// A1: histogram of dst >> shift over this block's edge slice.  Reads dst only (8 B/edge); edges whose dst is out of
+// range are dropped here and in A4 alike.  counts is bucket-major: counts[bucket * slice_blocks + block].
+__global__ __launch_bounds__(kCsrThreads) void bucket_count_kernel(const int64_t *__restrict__ dst, int64_t E, int64_t N, int shift,
+                                                                   int buckets, int64_t slice_edges, int slice_blocks,
+                                                                   uint32_t *__restrict__ counts, int32_t *__restrict__ err)
 {
     __shared__ uint32_t hist[kMaxBuckets];
-    __shared__ unsigned long long block_max;
     for (int b = threadIdx.x; b < buckets; b += blockDim.x) hist[b] = 0;
-    if (threadIdx.x == 0) block_max = 0;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * slice_edges;
     const int64_t hi = lo + slice_edges < E ? lo + slice_edges : E;
-    unsigned long long my_max = 0;
     bool bad = false;
-    for (int64_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
-        const int64_t s = src[e], d = dst[e];
-        if ((uint64_t)s >= (uint64_t)N || (uint64_t)d >= (uint64_t)N) {
-            bad = true;
-            // ids beyond N still count for the self-loop inference so the host can report them
-            const int64_t mx = s > d ? s : d;
-            if (mx >= 0 && (unsigned long long)mx + 1 > my_max) my_max = (unsigned long long)mx + 1;
-            continue;
+    int64_t e = lo + threadIdx.x;
+    for (; e + 3 * (int64_t)kCsrThreads < hi; e += 4 * (int64_t)kCsrThreads) {
+        int64_t d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = dst[e + k * (int64_t)kCsrThreads];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((uint64_t)d[k] < (uint64_t)N) atomicAdd(&hist[d[k] >> shift], 1u);
+            else bad = true;
         }
-        const unsigned long long mx = (unsigned long long)(s > d ? s : d) + 1;
-        my_max = mx > my_max ? mx : my_max;
-        atomicAdd(&hist[d >> shift], 1u);
     }
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(my_max, off);
-        my_max = o > my_max ? o : my_max;
+    for (; e < hi; e += kCsrThreads) {
+        const int64_t d = dst[e];
+        if ((uint64_t)d < (uint64_t)N) atomicAdd(&hist[d >> shift], 1u);
+        else bad = true;
     }
-    if ((threadIdx.x & (kWave - 1)) == 0 && my_max) atomicMax(&block_max, my_max);
     if (bad && err) *err = 1;
     __syncthreads();
-    for (int b = threadIdx.x; b < buckets; b += blockDim.x) counts[(int64_t)blockIdx.x * buckets + b] = hist[b];
-    if (threadIdx.x == 0 && block_max) atomicMax(n_self, block_max);
+    for (int b = threadIdx.x; b < buckets; b += blockDim.x) counts[(int64_t)b * slice_blocks + blockIdx.x] = hist[b];
 }
 
 // one wave per bucket: exclusive scan of the bucket's column over slice blocks (in place), bucket total out
@@ -103,14 +102,14 @@ __global__ __launch_bounds__(kCsrThreads) void bucket_offsets_kernel(uint32_t *_
     uint32_t carry = 0;
     for (int g0 = 0; g0 < slice_blocks; g0 += kWave) {
         const int g = g0 + lane;
-        const uint32_t x = g < slice_blocks ? counts[(int64_t)g * buckets + b] : 0u;
+        const uint32_t x = g < slice_blocks ? counts[(int64_t)b * slice_blocks + g] : 0u;
         uint32_t inc = x;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             const uint32_t o = __shfl_up(inc, off);
             if (lane >= off) inc += o;
         }
-        if (g < slice_blocks) counts[(int64_t)g * buckets + b] = carry + inc - x;
+        if (g < slice_blocks) counts[(int64_t)b * slice_blocks + g] = carry + inc - x;
         carry += __shfl(inc, kWave - 1);
     }
     if (lane == 0) bucket_total[b] = carry;
@@ -146,31 +145,64 @@ __global__ __launch_bounds__(kCsrThreads) void bucket_bases_kernel(unsigned long
     if (threadIdx.x == 0) rowptr[N] = (int64_t)carry_s;
 }
 
+// A4: scatter (src, dst) pairs into their bucket's segment; also reduces max(id) + 1 (the self-loop count of
+// add_self_loops, hashing.py:148).  An out-of-range src sets the error flag and is clamped to 0 (memory safe; the
+// host raises IndexError in strict mode), an out-of-range dst drops the edge exactly as A1 did.
 __global__ __launch_bounds__(kCsrThreads) void bucket_scatter_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                                                      int64_t E, int64_t N, int shift, int buckets, int64_t slice_edges,
-                                                                     const uint32_t *__restrict__ offsets /*[blocks][buckets]*/,
+                                                                     int slice_blocks, const uint32_t *__restrict__ offsets,
                                                                      const unsigned long long *__restrict__ bucket_base,
-                                                                     int2 *__restrict__ staged /*[E] (src, dst)*/)
+                                                                     int2 *__restrict__ staged /*[E] (src, dst)*/,
+                                                                     unsigned long long *__restrict__ n_self, int32_t *__restrict__ err)
 {
     __shared__ unsigned long long cursor[kMaxBuckets];
+    __shared__ unsigned long long block_max;
     for (int b = threadIdx.x; b < buckets; b += blockDim.x)
-        cursor[b] = bucket_base[b] + offsets[(int64_t)blockIdx.x * buckets + b];
+        cursor[b] = bucket_base[b] + offsets[(int64_t)b * slice_blocks + blockIdx.x];
+    if (threadIdx.x == 0) block_max = 0;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * slice_edges;
     const int64_t hi = lo + slice_edges < E ? lo + slice_edges : E;
-    for (int64_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
-        const int64_t s = src[e], d = dst[e];
-        if ((uint64_t)s >= (uint64_t)N || (uint64_t)d >= (uint64_t)N) continue;
+    int64_t my_max = -1;
+    bool bad = false;
+    auto place = [&](int64_t s, int64_t d) {
+        const int64_t mx = s > d ? s : d;
+        my_max = mx > my_max ? mx : my_max;
+        if ((uint64_t)d >= (uint64_t)N) return;
+        if ((uint64_t)s >= (uint64_t)N) { bad = true; s = 0; }
         const unsigned long long pos = atomicAdd(&cursor[d >> shift], 1ULL);
         staged[pos] = make_int2((int)s, (int)d);
+    };
+    int64_t e = lo + threadIdx.x;
+    for (; e + 3 * (int64_t)kCsrThreads < hi; e += 4 * (int64_t)kCsrThreads) {
+        int64_t sv[4], dv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sv[k] = src[e + k * (int64_t)kCsrThreads];
+            dv[k] = dst[e + k * (int64_t)kCsrThreads];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) place(sv[k], dv[k]);
     }
+    for (; e < hi; e += kCsrThreads) place(src[e], dst[e]);
+    unsigned long long m = my_max < 0 ? 0ULL : (unsigned long long)my_max + 1ULL;
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(&block_max, m);
+    if (bad && err) *err = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && block_max) atomicMax(n_self, block_max);
 }
 
 // one block per bucket
 __global__ __launch_bounds__(kFinishThreads) void bucket_finish_kernel(const int2 *__restrict__ staged,
                                                                        const unsigned long long *__restrict__ bucket_base,
                                                                        int buckets, int nodes_per_bucket, int64_t N,
-                                                                       int64_t *__restrict__ rowptr, int32_t *__restrict__ col)
+                                                                       int64_t *__restrict__ rowptr, int32_t *__restrict__ col,
+                                                                       int hub_threshold, int32_t *__restrict__ hub_rows,
+                                                                       int32_t *__restrict__ hub_count)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *cnt = smem;                       // [NB] counts, then cursors
@@ -182,11 +214,20 @@ __global__ __launch_bounds__(kFinishThreads) void bucket_finish_kernel(const int
     const unsigned long long seg_hi = (b + 1 < buckets) ? bucket_base[b + 1] : (unsigned long long)rowptr[N];
     for (int i = threadIdx.x; i < nodes_per_bucket; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    for (unsigned long long e = seg_lo + threadIdx.x; e < seg_hi; e += blockDim.x)
-        atomicAdd(&cnt[staged[e].y - (int)node0], 1u);
+    {
+        unsigned long long e = seg_lo + threadIdx.x;
+        for (; e + 3ULL * blockDim.x < seg_hi; e += 4ULL * blockDim.x) {
+            int y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = staged[e + (unsigned long long)k * blockDim.x].y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(&cnt[y[k] - (int)node0], 1u);
+        }
+        for (; e < seg_hi; e += blockDim.x) atomicAdd(&cnt[staged[e].y - (int)node0], 1u);
+    }
     __syncthreads();
     // exclusive scan of cnt[0..NB): each thread owns a contiguous run
-    const int per = nodes_per_bucket / kFinishThreads;  // NB is a multiple of 1024
+    const int per = nodes_per_bucket / (int)blockDim.x;  // NB is a power of two >= blockDim.x
     const int base = threadIdx.x * per;
     uint32_t run = 0;
     for (int k = 0; k < per; ++k) run += cnt[base + k];
@@ -206,15 +247,25 @@ __global__ __launch_bounds__(kFinishThreads) void bucket_finish_kernel(const int
         const uint32_t c = cnt[base + k];
         excl[base + k] = ex;
         if (node0 + base + k < N) rowptr[node0 + base + k] = (int64_t)(seg_lo + ex);
+        if (hub_rows && c > (uint32_t)hub_threshold) hub_rows[atomicAdd(hub_count, 1)] = (int32_t)(node0 + base + k);
         ex += c;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nodes_per_bucket; i += blockDim.x) cnt[i] = excl[i];
     __syncthreads();
-    for (unsigned long long e = seg_lo + threadIdx.x; e < seg_hi; e += blockDim.x) {
-        const int2 sd = staged[e];
-        const uint32_t pos = atomicAdd(&cnt[sd.y - (int)node0], 1u);
-        col[seg_lo + pos] = sd.x;
+    {
+        unsigned long long e = seg_lo + threadIdx.x;
+        for (; e + 3ULL * blockDim.x < seg_hi; e += 4ULL * blockDim.x) {
+            int2 sd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sd[k] = staged[e + (unsigned long long)k * blockDim.x];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) col[seg_lo + atomicAdd(&cnt[sd[k].y - (int)node0], 1u)] = sd[k].x;
+        }
+        for (; e < seg_hi; e += blockDim.x) {
+            const int2 sd = staged[e];
+            col[seg_lo + atomicAdd(&cnt[sd.y - (int)node0], 1u)] = sd.x;
+        }
     }
 }
 
@@ -232,7 +283,8 @@ extern "C" size_t ss_csr_workspace_bytes(int64_t N, int64_t E)
 }
 
 extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
-                            int64_t *n_self_loops_out, int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_)
+                            int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
+                            int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_)
 {
     using namespace ss;
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || !rowptr) return SS_ERR_INVALID_ARG;
@@ -248,7 +300,9 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     ws += align256((size_t)(p.buckets + 1) * 8);
     auto *staged = reinterpret_cast<int2 *>(ws);
 
+    if ((hub_rows == nullptr) != (hub_count == nullptr)) return SS_ERR_INVALID_ARG;
     if (n_self_loops_out && hipMemsetAsync(n_self_loops_out, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
+    if (hub_count && hipMemsetAsync(hub_count, 0, 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
     if (N == 0 || E == 0) {
         if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
         return SS_OK;
@@ -259,8 +313,8 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
         n_self = n_self_scratch;
         if (hipMemsetAsync(n_self, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(bucket_count_kernel, dim3(p.slice_blocks), dim3(kCsrThreads), 0, stream, src, dst, E, N, p.shift, p.buckets,
-                       p.slice_edges, counts, n_self, err_flag);
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(p.slice_blocks), dim3(kCsrThreads), 0, stream, dst, E, N, p.shift, p.buckets,
+                       p.slice_edges, p.slice_blocks, counts, err_flag);
     SS_LAUNCH_CHECK();
     const int waves_per_block = kCsrThreads / kWave;
     hipLaunchKernelGGL(bucket_offsets_kernel, dim3((p.buckets + waves_per_block - 1) / waves_per_block), dim3(kCsrThreads), 0, stream,
@@ -269,10 +323,10 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     hipLaunchKernelGGL(bucket_bases_kernel, dim3(1), dim3(kCsrThreads), 0, stream, bucket_total, p.buckets, rowptr, N);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(p.slice_blocks), dim3(kCsrThreads), 0, stream, src, dst, E, N, p.shift, p.buckets,
-                       p.slice_edges, counts, bucket_total, staged);
+                       p.slice_edges, p.slice_blocks, counts, bucket_total, staged, n_self, err_flag);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bucket_finish_kernel, dim3(p.buckets), dim3(kFinishThreads), (size_t)p.nodes_per_bucket * 8, stream, staged,
-                       bucket_total, p.buckets, p.nodes_per_bucket, N, rowptr, col);
+    hipLaunchKernelGGL(bucket_finish_kernel, dim3(p.buckets), dim3(p.nodes_per_bucket < kFinishThreads ? p.nodes_per_bucket : kFinishThreads), (size_t)p.nodes_per_bucket * 8, stream, staged,
+                       bucket_total, p.buckets, p.nodes_per_bucket, N, rowptr, col, (int)hub_threshold, hub_rows, hub_count);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

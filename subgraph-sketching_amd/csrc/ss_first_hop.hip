@@ -3,14 +3,19 @@
 // Hop-0 sketches are pure functions of the node id (reference hashing.py:118-137): row t of the MinHash
 // table is ((a_j * hv_t + b_j) mod 2^64 mod (2^61-1)) & 0xFFFFFFFF, row t of the HLL table has the single
 // register (hv_t & (m-1)) = rank(hv_t).  Reading them back from HBM for the first propagation
-// (hashing.py:160-161 at k = 1) costs (E' + N) * 768 B; recomputing them in registers costs ~25 VALU
-// issue slots per (neighbour, lane) and no table traffic at all -- the kernel reads only the CSR and
-// writes the hop-1 rows.  Results are identical to ss_minhash_init + ss_hll_init + ss_propagate.
+// (hashing.py:160-161 at k = 1) costs (E' + N) * 768 B; recomputing them in registers costs 3 integer
+// multiplies + 7 simple VALU per (neighbour, permutation) and no table traffic at all -- the kernel reads only
+// the CSR and writes the hop-1 rows.  Results are identical to ss_minhash_init + ss_hll_init + ss_propagate.
+// (VALU-bound: v_mul_lo_u32 / v_mad_u64_u32 issue at quarter rate, 16 cycles per wave64 on gfx950; measured
+// 0.17 ms vs 0.36 ms for init + propagate on the bench graph.)
 //
 // Mapping: one wavefront per destination row.  Lane l owns permutations l, l+64, .. (P/64 of them) and
 // HLL registers 4l..4l+3 (M = 256).  Neighbour ids are fetched 64 at a time (one coalesced load), every
-// lane hashes ITS neighbour (64 hashes in parallel), then the wave walks the batch with v_readlane:
-// the neighbour's hash is wave-uniform (SGPR pair), each lane evaluates its own permutations on it.
+// lane hashes ITS neighbour (64 hashes in parallel) and scatter-maxes that neighbour's single HLL register
+// into the wave's LDS row; then the wave walks the batch with v_readlane: the neighbour's hash is
+// wave-uniform (SGPR pair), each lane evaluates its own permutations on it.
+// Hub rows (see ss_propagate.hip) get a 16-wave workgroup: waves take alternate 64-neighbour batches and
+// combine through LDS atomics.
 #include "ss_common.hpp"
 
 namespace ss {
@@ -20,53 +25,22 @@ __device__ __forceinline__ uint32_t permuted_hash(uint64_t a, uint64_t b, uint64
     return (uint32_t)mod_mersenne61(a * hv + b);
 }
 
-template <int PPL /* permutations per lane = P / 64 */>
-__global__ __launch_bounds__(256) void first_hop_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t N,
-                                                        int64_t n_self_arg, const int64_t *__restrict__ n_self_dev,
-                                                        const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
-                                                        uint32_t *__restrict__ mh_out, int p, uint8_t *__restrict__ hll_out,
-                                                        float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm)
+// processes neighbour batches base = first_batch*64, += batch_stride*64 of one row; acc / hll_row accumulate
+template <int PPL>
+__device__ __forceinline__ void first_hop_walk(const int32_t *__restrict__ nb, int deg, int total, int64_t self_row, int first_batch,
+                                               int batch_stride, int p, const uint64_t (&a)[PPL], const uint64_t (&b)[PPL],
+                                               uint32_t (&acc)[PPL], uint32_t *hll_row, int lane)
 {
-    __shared__ EstimatorLds lds;
-    __shared__ uint32_t hll_rows[256 / kWave][256];  // one u32 per HLL register and wave (LDS scatter-max target)
-    const bool want_cards = cards_out != nullptr;
-    EstimatorTables est;
-    if (want_cards) est = stage_tables(lds, prm);
-
-    constexpr int P = PPL * kWave;
-    const int lane = threadIdx.x & (kWave - 1);
-    // wave-uniform row id (readfirstlane makes the uniformity visible to the compiler: scalar loads, scalar loop control)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + wave;
-    if (i >= N) return;
-
-    uint64_t a[PPL], b[PPL];
-    uint32_t acc[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-        a[q] = pa[lane + kWave * q];
-        b[q] = pb[lane + kWave * q];
-        acc[q] = 0xFFFFFFFFu;
-    }
-    uint32_t *my_row = hll_rows[wave];
-    *reinterpret_cast<u32x4 *>(my_row + 4 * lane) = u32x4{0u, 0u, 0u, 0u};
-
-    const int64_t rb = rowptr[i];
-    const int deg = (int)(rowptr[i + 1] - rb);
-    const int64_t n_self = n_self_dev ? *n_self_dev : n_self_arg;
-    const int total = deg + (i < n_self ? 1 : 0);
-    const int32_t *nb = col + rb;
-
-    for (int base = 0; base < total; base += kWave) {
+    for (int base = first_batch * kWave; base < total; base += batch_stride * kWave) {
         const int t = base + lane;
-        const int64_t nid = t < deg ? (int64_t)nb[t] : i;      // t == deg is the implicit self loop; t > deg unused
+        const int64_t nid = t < deg ? (int64_t)nb[t] : self_row;  // t == deg is the implicit self loop; t > deg unused
         const uint64_t hv = hash_u64((uint64_t)(nid + 1));
         const uint32_t hv_lo = (uint32_t)hv, hv_hi = (uint32_t)(hv >> 32);
-        // HLL (hashing.py:126-137): every lane scatters ITS neighbour's single register into the wave's LDS row
+        // HLL (hashing.py:126-137): every lane scatters ITS neighbour's single register into the LDS row
         if (t < total) {
             const uint64_t bits = hv >> p;
             const int bl = bits ? 64 - __builtin_clzll(bits) : 0;
-            atomicMax(&my_row[hv_lo & 255u], (uint32_t)((64 - p) - bl + 1));
+            atomicMax(&hll_row[hv_lo & 255u], (uint32_t)((64 - p) - bl + 1));
         }
         // MinHash: walk the batch; the neighbour's hash is wave-uniform, each lane evaluates its own permutations
         const int cnt = total - base < kWave ? total - base : kWave;
@@ -94,6 +68,51 @@ __global__ __launch_bounds__(256) void first_hop_kernel(const int64_t *__restric
             }
         }
     }
+}
+
+// one lane-quad of HLL registers (u32 each in LDS) -> packed bytes, stored + optional stats for the cardinality
+__device__ __forceinline__ uint32_t pack_hll_quad(const uint32_t *row, int lane)
+{
+    const u32x4 r4 = *reinterpret_cast<const u32x4 *>(row + 4 * lane);
+    return r4.x | (r4.y << 8) | (r4.z << 16) | (r4.w << 24);
+}
+
+template <int PPL /* permutations per lane = P / 64 */>
+__global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
+                                                        uint32_t *__restrict__ mh_out, int p, uint8_t *__restrict__ hll_out,
+                                                        float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm,
+                                                        bool skip_hubs)
+{
+    __shared__ EstimatorLds lds;
+    __shared__ __attribute__((aligned(16))) uint32_t hll_rows[256 / kWave][256];  // one u32 per register and wave
+    const bool want_cards = cards_out != nullptr;
+    EstimatorTables est;
+    if (want_cards) est = stage_tables(lds, prm);
+
+    constexpr int P = PPL * kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + wave;
+    if (i >= g.N) return;
+    const int64_t rb = g.rowptr[i];
+    const int deg = (int)(g.rowptr[i + 1] - rb);
+    if (skip_hubs && deg > g.hub_threshold) return;  // left to first_hop_hub_kernel
+
+    uint64_t a[PPL], b[PPL];
+    uint32_t acc[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        a[q] = pa[lane + kWave * q];
+        b[q] = pb[lane + kWave * q];
+        acc[q] = 0xFFFFFFFFu;
+    }
+    uint32_t *my_row = hll_rows[wave];
+    *reinterpret_cast<u32x4 *>(my_row + 4 * lane) = u32x4{0u, 0u, 0u, 0u};
+
+    const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
+    const int total = deg + (i < n_self ? 1 : 0);
+    first_hop_walk<PPL>(g.col + rb, deg, total, i, 0, 1, p, a, b, acc, my_row, lane);
+
     if (total == 0) {
 #pragma unroll
         for (int q = 0; q < PPL; ++q) acc[q] = 0u;  // no in-edge, no self loop: all-zero row (PyG default)
@@ -102,34 +121,114 @@ __global__ __launch_bounds__(256) void first_hop_kernel(const int64_t *__restric
     for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = acc[q];
     // the wave's LDS row is only touched by this wave: a wave-level fence orders the atomics before the read
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const u32x4 r4 = *reinterpret_cast<const u32x4 *>(my_row + 4 * lane);
-    const uint32_t regs = r4.x | (r4.y << 8) | (r4.z << 16) | (r4.w << 24);  // HLL registers 4*lane .. 4*lane+3
+    const uint32_t regs = pack_hll_quad(my_row, lane);  // HLL registers 4*lane .. 4*lane+3
     *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
 
     if (want_cards) {
-        int zeros = 0;
+        int nonzero = 0;
         float hsum = 0.0f;
-        hll_dword_stats(regs, zeros, hsum);
+        hll_dword_stats(regs, nonzero, hsum);
         for (int off = 1; off < kWave; off <<= 1) {
-            zeros += __shfl_xor(zeros, off);
+            nonzero += __shfl_xor(nonzero, off);
             hsum += __shfl_xor(hsum, off);
         }
-        if (lane == 0) cards_out[i * cards_stride] = hll_estimate(est, zeros, hsum);
+        if (lane == 0) cards_out[i * cards_stride] = hll_estimate(est, 256 - nonzero, hsum);
     }
+}
+
+constexpr int kHubThreads = 1024;
+constexpr int kHubWaves = kHubThreads / kWave;
+constexpr int kHubGrid = 512;
+
+template <int PPL>
+__global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g, const uint64_t *__restrict__ pa,
+                                                                    const uint64_t *__restrict__ pb, uint32_t *__restrict__ mh_out, int p,
+                                                                    uint8_t *__restrict__ hll_out, float *__restrict__ cards_out,
+                                                                    int64_t cards_stride, ss_hll_params prm)
+{
+    __shared__ EstimatorLds lds;
+    __shared__ __attribute__((aligned(16))) uint32_t hll_row[256];
+    __shared__ uint32_t mh_row[PPL * kWave];
+    const int n_hubs = *g.hub_count;
+    if ((int)blockIdx.x >= n_hubs) return;  // the common case (no hub rows) costs one scalar load per workgroup
+    const bool want_cards = cards_out != nullptr;
+    EstimatorTables est;
+    if (want_cards) est = stage_tables(lds, prm);
+    constexpr int P = PPL * kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    uint64_t a[PPL], b[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        a[q] = pa[lane + kWave * q];
+        b[q] = pb[lane + kWave * q];
+    }
+    const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
+    for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
+        const int64_t i = g.hub_rows[h];
+        const int64_t rb = g.rowptr[i];
+        const int deg = (int)(g.rowptr[i + 1] - rb);
+        const int total = deg + (i < n_self ? 1 : 0);
+        if (threadIdx.x < 256) hll_row[threadIdx.x] = 0u;
+        if (threadIdx.x < P) mh_row[threadIdx.x] = 0xFFFFFFFFu;
+        __syncthreads();
+        uint32_t acc[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
+        first_hop_walk<PPL>(g.col + rb, deg, total, i, wave, kHubWaves, p, a, b, acc, hll_row, lane);
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) atomicMin(&mh_row[lane + kWave * q], acc[q]);
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = mh_row[lane + kWave * q];
+            const uint32_t regs = pack_hll_quad(hll_row, lane);
+            *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
+            if (want_cards) {
+                int nonzero = 0;
+                float hsum = 0.0f;
+                hll_dword_stats(regs, nonzero, hsum);
+                for (int off = 1; off < kWave; off <<= 1) {
+                    nonzero += __shfl_xor(nonzero, off);
+                    hsum += __shfl_xor(hsum, off);
+                }
+                if (lane == 0) cards_out[i * cards_stride] = hll_estimate(est, 256 - nonzero, hsum);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int PPL>
+int launch_first_hop(const GraphArgs &g, const uint64_t *a, const uint64_t *b, uint32_t *mh_out, int p, uint8_t *hll_out,
+                     float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t s)
+{
+    const int64_t blocks = (g.N + 3) / 4;
+    const bool hubs = g.hub_rows && g.hub_count;
+    hipLaunchKernelGGL((first_hop_kernel<PPL>), dim3((unsigned)blocks), dim3(256), 0, s, g, a, b, mh_out, p, hll_out, cards_out,
+                       cards_stride, prm, hubs);
+    SS_LAUNCH_CHECK();
+    if (hubs) {
+        hipLaunchKernelGGL((first_hop_hub_kernel<PPL>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p, hll_out, cards_out,
+                           cards_stride, prm);
+        SS_LAUNCH_CHECK();
+    }
+    return SS_OK;
 }
 
 }  // namespace ss
 
-extern "C" int ss_first_hop(const int64_t *rowptr, const int32_t *col, int64_t N, int64_t n_self_loops,
-                            const int64_t *n_self_loops_dev, const uint64_t *a, const uint64_t *b, int32_t P,
+extern "C" int ss_first_hop(const ss_csr_graph *graph, const uint64_t *a, const uint64_t *b, int32_t P,
                             uint32_t *mh_out, int32_t p, uint8_t *hll_out, float *cards_out, int64_t cards_stride,
                             const ss_hll_params *prm, void *stream)
 {
     using namespace ss;
-    if (N < 0 || !rowptr) return SS_ERR_INVALID_ARG;
+    if (!graph || graph->num_nodes < 0 || !graph->rowptr) return SS_ERR_INVALID_ARG;
     if (p != 8 || P <= 0 || P % kWave || P > 256) return SS_ERR_UNSUPPORTED;  // caller falls back to init + propagate
+    const int64_t N = graph->num_nodes;
     if (N == 0) return SS_OK;
     if (!a || !b || !mh_out || !hll_out || N >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
+    if ((graph->hub_rows == nullptr) != (graph->hub_count == nullptr)) return SS_ERR_INVALID_ARG;
     ss_hll_params p0 = {};
     if (cards_out) {
         const int rc = check_params(prm);
@@ -137,18 +236,12 @@ extern "C" int ss_first_hop(const int64_t *rowptr, const int32_t *col, int64_t N
         if (prm->p != p) return SS_ERR_INVALID_ARG;
         p0 = *prm;
     }
-    const int64_t blocks = (N + 3) / 4;
+    const GraphArgs g = to_args(*graph);
     hipStream_t s = (hipStream_t)stream;
-#define SS_LAUNCH_FIRST_HOP(PPL)                                                                                              \
-    hipLaunchKernelGGL((first_hop_kernel<PPL>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, N, n_self_loops,         \
-                       n_self_loops_dev, a, b, mh_out, (int)p, hll_out, cards_out, cards_stride, p0)
     switch (P / kWave) {
-        case 1: SS_LAUNCH_FIRST_HOP(1); break;
-        case 2: SS_LAUNCH_FIRST_HOP(2); break;
-        case 3: SS_LAUNCH_FIRST_HOP(3); break;
-        default: SS_LAUNCH_FIRST_HOP(4); break;
+        case 1: return launch_first_hop<1>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, p0, s);
+        case 2: return launch_first_hop<2>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, p0, s);
+        case 3: return launch_first_hop<3>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, p0, s);
+        default: return launch_first_hop<4>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, p0, s);
     }
-#undef SS_LAUNCH_FIRST_HOP
-    SS_LAUNCH_CHECK();
-    return SS_OK;
 }

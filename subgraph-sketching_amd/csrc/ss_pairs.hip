@@ -27,13 +27,53 @@ __device__ __forceinline__ int eq4(u32x4 a, u32x4 b)
     return (int)(a.x == b.x) + (int)(a.y == b.y) + (int)(a.z == b.z) + (int)(a.w == b.w);
 }
 
-__device__ __forceinline__ void union_stats(u32x4 a, u32x4 b, int &zeros, float &hsum)
+// generic path: union of two 16-register chunks -> non-zero count and harmonic sum
+__device__ __forceinline__ void union_stats(u32x4 a, u32x4 b, int &nonzero, float &hsum)
 {
     const u32x4 m = bytemax16(a, b);
-    hll_dword_stats(m.x, zeros, hsum);
-    hll_dword_stats(m.y, zeros, hsum);
-    hll_dword_stats(m.z, zeros, hsum);
-    hll_dword_stats(m.w, zeros, hsum);
+    hll_dword_stats(m.x, nonzero, hsum);
+    hll_dword_stats(m.y, nonzero, hsum);
+    hll_dword_stats(m.z, nonzero, hsum);
+    hll_dword_stats(m.w, nonzero, hsum);
+}
+
+// fast path: a 16-register HLL chunk pre-digested once per row so that each of the h^2 unions costs
+// 4 instructions per dword: bf16 patterns of 2^-r (even / odd registers; max of registers == unsigned min of
+// patterns) and a 16-bit "register is zero" mask (union register zero <=> zero in both rows).
+struct HllChunk {
+    uint32_t pe[4], po[4];
+    uint32_t zero_mask;
+};
+
+__device__ __forceinline__ HllChunk digest_chunk(u32x4 x)
+{
+    HllChunk c;
+    const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+    uint32_t nzbits = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        c.pe[d] = regs_even_to_bf16(w[d]);
+        c.po[d] = regs_odd_to_bf16(w[d]);
+        nzbits |= nonzero_byte_flags(w[d]) >> (7 - d);  // flags live in bits 7,15,23,31 -> bits d, 8+d, 16+d, 24+d
+    }
+    c.zero_mask = ~nzbits & 0x0F0F0F0Fu;
+    return c;
+}
+
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(x, y));
+}
+
+__device__ __forceinline__ void union_stats_digested(const HllChunk &a, const HllChunk &b, int &zeros, float &hsum)
+{
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        hsum = dot2_ones(pk_min_u16(a.pe[d], b.pe[d]), hsum);
+        hsum = dot2_ones(pk_min_u16(a.po[d], b.po[d]), hsum);
+    }
+    zeros += __builtin_popcount(a.zero_mask & b.zero_mask);
 }
 
 // feature algebra of get_subgraph_features (hashing.py:276-320); I is indexed [k1-1][k2-1].
@@ -116,7 +156,7 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
         constexpr int CMPL = TP / 4 / kRow;   // MinHash chunks per lane
         constexpr int CHPL = TM / 16 / kRow;  // HLL chunks per lane
         static_assert(CMPL >= 1 && CHPL >= 1 && (TP / 4) % kRow == 0 && (TM / 16) % kRow == 0, "fast path shape");
-        u32x4 mu[H][CMPL], mv[H][CMPL], hu[H][CHPL], hv[H][CHPL];
+        u32x4 mu[H][CMPL], mv[H][CMPL], xu[H][CHPL], xv[H][CHPL];
 #pragma unroll
         for (int k = 0; k < H; ++k) {
 #pragma unroll
@@ -126,10 +166,18 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
             }
 #pragma unroll
             for (int c = 0; c < CHPL; ++c) {
-                hu[k][c] = *reinterpret_cast<const u32x4 *>(tabs.hll[k] + u * TM + 16 * (l + kRow * c));
-                hv[k][c] = *reinterpret_cast<const u32x4 *>(tabs.hll[k] + v * TM + 16 * (l + kRow * c));
+                xu[k][c] = *reinterpret_cast<const u32x4 *>(tabs.hll[k] + u * TM + 16 * (l + kRow * c));
+                xv[k][c] = *reinterpret_cast<const u32x4 *>(tabs.hll[k] + v * TM + 16 * (l + kRow * c));
             }
         }
+        HllChunk hu[H][CHPL], hv[H][CHPL];
+#pragma unroll
+        for (int k = 0; k < H; ++k)
+#pragma unroll
+            for (int c = 0; c < CHPL; ++c) {
+                hu[k][c] = digest_chunk(xu[k][c]);
+                hv[k][c] = digest_chunk(xv[k][c]);
+            }
 #pragma unroll
         for (int k1 = 0; k1 < H; ++k1)
 #pragma unroll
@@ -139,7 +187,7 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
 #pragma unroll
                 for (int c = 0; c < CMPL; ++c) match += eq4(mu[k1][c], mv[k2][c]);
 #pragma unroll
-                for (int c = 0; c < CHPL; ++c) union_stats(hu[k1][c], hv[k2][c], zeros, hsum);
+                for (int c = 0; c < CHPL; ++c) union_stats_digested(hu[k1][c], hv[k2][c], zeros, hsum);
                 mz[k1 * H + k2] = row16_sum_i((match << 20) | zeros);
                 hs[k1 * H + k2] = row16_sum_f(hsum);
             }
@@ -149,15 +197,16 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
         for (int k1 = 0; k1 < H; ++k1)
 #pragma unroll
             for (int k2 = 0; k2 < H; ++k2) {
-                int match = 0, zeros = 0;
+                int match = 0, nonzero = 0;
                 float hsum = 0.0f;
                 for (int c = l; c < CM; c += kRow)
                     match += eq4(*reinterpret_cast<const u32x4 *>(tabs.mh[k1] + u * P + 4 * c),
                                  *reinterpret_cast<const u32x4 *>(tabs.mh[k2] + v * P + 4 * c));
-                for (int c = l; c < CH; c += kRow)
+                int chunks = 0;
+                for (int c = l; c < CH; c += kRow, ++chunks)
                     union_stats(*reinterpret_cast<const u32x4 *>(tabs.hll[k1] + u * M + 16 * c),
-                                *reinterpret_cast<const u32x4 *>(tabs.hll[k2] + v * M + 16 * c), zeros, hsum);
-                mz[k1 * H + k2] = row16_sum_i((match << 20) | zeros);
+                                *reinterpret_cast<const u32x4 *>(tabs.hll[k2] + v * M + 16 * c), nonzero, hsum);
+                mz[k1 * H + k2] = row16_sum_i((match << 20) | (16 * chunks - nonzero));
                 hs[k1 * H + k2] = row16_sum_f(hsum);
             }
     }

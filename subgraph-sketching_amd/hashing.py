@@ -229,17 +229,29 @@ def _packed_hll_of(t, device):
 # ------------------------------------------------------------------------------------------------
 # CSR cache
 # ------------------------------------------------------------------------------------------------
-class CsrGraph(object):
-    """destination-grouped adjacency resident on the device.  `n_self_dev` (device int64[1]) holds
-    max(edge_index) + 1 as computed by ss_csr_build; `use_inferred_self_loops` says whether the propagation adds
-    those implicit self loops (build_hash_tables) or none (hll_prop / minhash_prop get them explicitly)."""
+HUB_THRESHOLD = 512  # rows with more in-edges than this are propagated by a 16-wave workgroup instead of one wavefront
 
-    def __init__(self, rowptr, col, num_nodes, n_self_dev, err):
+
+class CsrGraph(object):
+    """destination-grouped adjacency resident on the device (struct ss_csr_graph + the tensors it points to).
+    `n_self_dev` (device int64[1]) holds max(edge_index) + 1 as computed by ss_csr_build; `use_inferred_self_loops`
+    says whether the propagation adds those implicit self loops (build_hash_tables) or none (hll_prop / minhash_prop
+    receive them explicitly in edge_index)."""
+
+    def __init__(self, rowptr, col, num_nodes, n_self_dev, err, hub_rows, hub_count, hub_threshold):
         self.rowptr, self.col, self.num_nodes, self.n_self_dev, self.err = rowptr, col, num_nodes, n_self_dev, err
+        self.hub_rows, self.hub_count, self.hub_threshold = hub_rows, hub_count, hub_threshold
         self.use_inferred_self_loops = False
 
+    def struct(self):
+        return _native.CsrGraphStruct(rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(), num_nodes=self.num_nodes,
+                                      n_self_loops=0,
+                                      n_self_loops_dev=self.n_self_dev.data_ptr() if self.use_inferred_self_loops else None,
+                                      hub_threshold=self.hub_threshold, reserved=0, hub_rows=self.hub_rows.data_ptr(),
+                                      hub_count=self.hub_count.data_ptr())
 
-def build_csr(edge_index, num_nodes, device, check=True):
+
+def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
     """CSR-by-destination of edge_index [2, E] (flow source -> target, reference hashing.py:34,44).
     check=True synchronises once to raise IndexError for endpoints outside [0, num_nodes)."""
     lib = _native.lib()
@@ -248,20 +260,25 @@ def build_csr(edge_index, num_nodes, device, check=True):
         raise ValueError('edge_index must have shape [2, num_edges]')
     src, dst = ei[0].contiguous(), ei[1].contiguous()
     E = src.numel()
+    hub_threshold = HUB_THRESHOLD if hub_threshold is None else hub_threshold
     rowptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=device)
     col = torch.empty(max(E, 1), dtype=torch.int32, device=device)
-    flags = torch.zeros(2, dtype=torch.int64, device=device)  # [0] = n_self (written by the kernel), [1] = error flag
-    n_self_dev, err = flags[0:1], flags[1:2].view(torch.int32)[0:1]
+    flags = torch.zeros(2, dtype=torch.int64, device=device)  # [0] = n_self (written by the kernel), [1] = error flag | hub count
+    n_self_dev = flags[0:1]
+    small = flags[1:2].view(torch.int32)
+    err, hub_count = small[0:1], small[1:2]
+    hub_rows = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=device)
     ws_bytes = lib.ss_csr_workspace_bytes(num_nodes, E)
     if ws_bytes == 0:
         raise NotImplementedError(f'graphs with {num_nodes} nodes are not supported by the CSR builder')
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
     with _Span('csr_build', device):
-        _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(n_self_dev), _ptr(err),
-                                       _ptr(ws), ws_bytes, _stream(device)), 'ss_csr_build')
+        _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(n_self_dev),
+                                       hub_threshold, _ptr(hub_rows), _ptr(hub_count), _ptr(err), _ptr(ws), ws_bytes,
+                                       _stream(device)), 'ss_csr_build')
     if check and int(err.item()):
         raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
-    return CsrGraph(rowptr, col, num_nodes, n_self_dev, err)
+    return CsrGraph(rowptr, col, num_nodes, n_self_dev, err, hub_rows, hub_count, hub_threshold)
 
 
 class _CsrCache(object):
@@ -293,11 +310,10 @@ def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, param
     P = mh_in.size(1) if mh_in is not None else 0
     M = hll_in.size(1) if hll_in is not None else 0
     prm = byref(params.struct) if params is not None else None
-    n_self_dev = csr.n_self_dev if csr.use_inferred_self_loops else None
+    graph = csr.struct()
     with _Span('propagate', device):
-        _native.check(_native.lib().ss_propagate(_ptr(csr.rowptr), _ptr(csr.col), N, 0, _ptr(n_self_dev), _ptr(mh_in),
-                                                 _ptr(mh_out), P, _ptr(hll_in), _ptr(hll_out), M, _ptr(cards_out),
-                                                 cards_stride, prm, _stream(device)), 'ss_propagate')
+        _native.check(_native.lib().ss_propagate(byref(graph), _ptr(mh_in), _ptr(mh_out), P, _ptr(hll_in), _ptr(hll_out), M,
+                                                 _ptr(cards_out), cards_stride, prm, _stream(device)), 'ss_propagate')
     return mh_out, hll_out
 
 
@@ -509,10 +525,10 @@ class ElphHashes(object):
         ab = self._perms(device)
         mh = torch.empty((num_nodes, self.num_perm), dtype=torch.int32, device=device)
         hll = torch.empty((num_nodes, self.m), dtype=torch.uint8, device=device)
+        graph = csr.struct()
         with _Span('first_hop', device):
-            rc = _native.lib().ss_first_hop(_ptr(csr.rowptr), _ptr(csr.col), num_nodes, 0, _ptr(csr.n_self_dev), _ptr(ab[0]),
-                                            _ptr(ab[1]), self.num_perm, _ptr(mh), self.p, _ptr(hll), _ptr(cards),
-                                            self.max_hops, byref(params.struct), _stream(device))
+            rc = _native.lib().ss_first_hop(byref(graph), _ptr(ab[0]), _ptr(ab[1]), self.num_perm, _ptr(mh), self.p, _ptr(hll),
+                                            _ptr(cards), self.max_hops, byref(params.struct), _stream(device))
         if rc == -4:  # SS_ERR_UNSUPPORTED: no fused variant for this (num_perm, p)
             return None, None
         _native.check(rc, 'ss_first_hop')
