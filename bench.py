@@ -117,6 +117,11 @@ def main():
     ap.add_argument('--config', default='collab', choices=sorted(CONFIGS), help='synthetic shape (default: BASELINE configs[1])')
     ap.add_argument('--graph', default='uniform', choices=['uniform', 'powerlaw'])
     ap.add_argument('--alpha', type=float, default=0.5, help='power-law exponent of the endpoint weights')
+    ap.add_argument('--api', default='build_query', choices=['build_query', 'elph', 'buddy'],
+                    help='build_query (default, the BASELINE metric): build_hash_tables + get_subgraph_features per step; '
+                         'elph: the exact call sequence of ELPH.forward (models/elph.py:186-213) + one query per step; '
+                         'buddy: one build amortised over --buddy-batches query batches (datasets/elph.py:200-208)')
+    ap.add_argument('--buddy-batches', type=int, default=40)
     a = ap.parse_args()
     global N_NODES, E_UND, H, BATCH, GRAPH_KIND, PL_ALPHA
     cfg = CONFIGS[a.config]
@@ -147,12 +152,43 @@ def main():
     links = torch.from_numpy(links_np).to(dev)
     gathered = torch.empty((world * BATCH, H * (H + 2)), dtype=torch.float32, device=dev) if launched else None
 
-    def step():
+    def step_build_query():
         table, cards = eh.build_hash_tables(N_NODES, ei)
         f = eh.get_subgraph_features(links, table, cards)
         if launched:
             dist.all_gather_into_tensor(gathered, f)
         return f
+
+    elph_state = {}
+
+    def step_elph():
+        """what reference models/elph.py:186-213 + runners/train.py:204 execute per training step"""
+        loops = torch.arange(N_NODES, device=dev).repeat(2, 1)
+        hash_edge_index = torch.cat([ei, loops], dim=1)                      # add_self_loops
+        if 'mh0' not in elph_state:                                          # init once (elph.py:189-192)
+            elph_state['mh0'], elph_state['hll0'] = eh.initialise_minhash(N_NODES), eh.initialise_hll(N_NODES)
+        table = {0: {'minhash': elph_state['mh0'], 'hll': elph_state['hll0']}}
+        cards = torch.zeros((N_NODES, H), device=dev)
+        for k in range(1, H + 1):
+            table[k] = {'hll': eh.hll_prop(table[k - 1]['hll'], hash_edge_index),
+                        'minhash': eh.minhash_prop(table[k - 1]['minhash'], hash_edge_index)}
+            cards[:, k - 1] = eh.hll_count(table[k]['hll'])
+        f = eh.get_subgraph_features(links, table, cards)
+        if launched:
+            dist.all_gather_into_tensor(gathered, f)
+        return f
+
+    def step_buddy():
+        """one build, then --buddy-batches batches of B pairs; a 'step' is one batch incl. its share of the build"""
+        table, cards = eh.build_hash_tables(N_NODES, ei)
+        for _ in range(a.buddy_batches):
+            f = eh.get_subgraph_features(links, table, cards)
+            if launched:
+                dist.all_gather_into_tensor(gathered, f)
+        return f
+
+    step = {'build_query': step_build_query, 'elph': step_elph, 'buddy': step_buddy}[a.api]
+    pairs_per_step = BATCH * (a.buddy_batches if a.api == 'buddy' else 1)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -191,16 +227,18 @@ def main():
 
     out = {
         'metric': 'edge-pairs/sec subgraph-feature extraction (build+query)',
-        'value': world * BATCH * a.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps,
+        'value': world * pairs_per_step * a.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'u32/u8 sketches, f32 estimator', 'data': 'synthetic',
         'config': {'workload': f'ogbl-{a.config}-like synthetic {a.graph} graph' + (' (BASELINE configs[1])' if a.config == 'collab' else '') +
-                               ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps',
+                               ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps' +
+                               ('' if a.api == 'build_query' else f' [api mode: {a.api}]'),
                    'num_nodes': N_NODES, 'directed_edges': 2 * E_UND, 'max_hash_hops': H, 'minhash_num_perm': P, 'hll_p': HLL_P,
-                   'pairs_per_step_per_gpu': BATCH, 'global_pairs_per_step': world * BATCH,
+                   'pairs_per_step_per_gpu': pairs_per_step, 'global_pairs_per_step': world * pairs_per_step,
                    'parallelism': f'edge-batch sharded x{world}, sketch table replicated, all_gather of features',
                    'hll_tables': eh.hll_tables.provenance},
-        'roofline': {'kernel': 'ss::propagate_kernel<128,256>' + ('' if H > 1 else ' (not launched at h=1)'), 'bound': 'hbm', 'achieved': prop_bytes / (prop_ms * 1e-3) / 1e9 if prop_ms else None,
+        'roofline': {'kernel': 'ss::propagate_kernel<128,256>' + ('' if H > 1 else ' (not launched at h=1)') +
+                               (' [elph api mode launches it per sketch: the bytes model below does not apply]' if a.api == 'elph' else ''), 'bound': 'hbm', 'achieved': prop_bytes / (prop_ms * 1e-3) / 1e9 if prop_ms else None,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': prop_bytes / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if prop_ms else None, 'traffic': traffic,
                      'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n},

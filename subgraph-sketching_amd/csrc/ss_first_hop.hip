@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
 
 constexpr int kHubThreads = 1024;
 constexpr int kHubWaves = kHubThreads / kWave;
-constexpr int kHubGrid = 512;
+constexpr int kHubGrid = 256;  // one workgroup per CU; workgroups beyond the hub count exit at once
 
 template <int PPL>
 __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g, const uint64_t *__restrict__ pa,

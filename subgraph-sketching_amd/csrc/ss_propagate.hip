@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
 // ---- hub rows: one 1024-thread workgroup (16 wavefronts) per row; P = 128, M = 256 only -------------------------
 constexpr int kHubThreads = 1024;
 constexpr int kHubWaves = kHubThreads / kWave;
-constexpr int kHubGrid = 512;
+constexpr int kHubGrid = 256;  // one workgroup per CU; workgroups beyond the hub count exit at once
 
 __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g, const uint32_t *__restrict__ mh_in,
                                                                     uint32_t *__restrict__ mh_out, const uint8_t *__restrict__ hll_in,

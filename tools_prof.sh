@@ -1,8 +1,13 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): bash tools_prof.sh <tag> [bench args]
-# rocprofv3 kernel trace of bench.py -> gpurun_out/prof_<tag>/ (csv), summarised by tools_prof_summary.py
+# 1) rocprofv3 --kernel-trace --stats of bench.py  2) two PMC passes (FETCH_SIZE, WRITE_SIZE) in their own runs.
+# Outputs land in gpurun_out/prof_<tag>/ ; tools/summarise_prof.py turns them into profiles/<tag>_*.{csv,json}
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o $TAG -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
+if [ -z "$NO_PMC" ]; then
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG -o ${TAG}_fetch -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG -o ${TAG}_write -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
+fi
 ls $R/gpurun_out/prof_$TAG
