@@ -63,9 +63,15 @@ inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
 // range are dropped here and in A4 alike.  counts is bucket-major: counts[bucket * slice_blocks + block].
 __global__ __launch_bounds__(kCsrThreads) void bucket_count_kernel(const int64_t *__restrict__ dst, int64_t E, int64_t N, int shift,
                                                                    int buckets, int64_t slice_edges, int slice_blocks,
-                                                                   uint32_t *__restrict__ counts, int32_t *__restrict__ err)
+                                                                   uint32_t *__restrict__ counts, int32_t *__restrict__ err,
+                                                                   unsigned long long *__restrict__ n_self, int32_t *__restrict__ hub_count)
 {
     __shared__ uint32_t hist[kMaxBuckets];
+    // outputs of the LATER kernels of this build (A4: n_self, B: hub_count) are cleared here: saves two memset launches
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *n_self = 0ULL;
+        if (hub_count) *hub_count = 0;
+    }
     for (int b = threadIdx.x; b < buckets; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * slice_edges;
@@ -301,20 +307,16 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     auto *staged = reinterpret_cast<int2 *>(ws);
 
     if ((hub_rows == nullptr) != (hub_count == nullptr)) return SS_ERR_INVALID_ARG;
-    if (n_self_loops_out && hipMemsetAsync(n_self_loops_out, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
-    if (hub_count && hipMemsetAsync(hub_count, 0, 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
     if (N == 0 || E == 0) {
+        if (n_self_loops_out && hipMemsetAsync(n_self_loops_out, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
+        if (hub_count && hipMemsetAsync(hub_count, 0, 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
         if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
         return SS_OK;
     }
     unsigned long long *n_self = reinterpret_cast<unsigned long long *>(n_self_loops_out);
-    unsigned long long *n_self_scratch = bucket_total + p.buckets;  // spare slot when the caller does not want it
-    if (!n_self) {
-        n_self = n_self_scratch;
-        if (hipMemsetAsync(n_self, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
-    }
+    if (!n_self) n_self = bucket_total + p.buckets;  // spare workspace slot when the caller does not want the value
     hipLaunchKernelGGL(bucket_count_kernel, dim3(p.slice_blocks), dim3(kCsrThreads), 0, stream, dst, E, N, p.shift, p.buckets,
-                       p.slice_edges, p.slice_blocks, counts, err_flag);
+                       p.slice_edges, p.slice_blocks, counts, err_flag, n_self, hub_count);
     SS_LAUNCH_CHECK();
     const int waves_per_block = kCsrThreads / kWave;
     hipLaunchKernelGGL(bucket_offsets_kernel, dim3((p.buckets + waves_per_block - 1) / waves_per_block), dim3(kCsrThreads), 0, stream,

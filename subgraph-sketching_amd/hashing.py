@@ -71,6 +71,26 @@ def _ptr(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
+_ERROR_FLAGS = {}
+
+
+def _error_flag(device):
+    """one persistent device int32 per GPU that kernels set to 1 on out-of-range ids (never allocated per call)"""
+    key = str(device)
+    if key not in _ERROR_FLAGS:
+        _ERROR_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _ERROR_FLAGS[key]
+
+
+def _take_error(device):
+    """synchronising read-and-clear of the device error flag"""
+    flag = _error_flag(device)
+    bad = bool(int(flag.item()))
+    if bad:
+        flag.zero_()
+    return bad
+
+
 def _check_sizes(num_perm, p):
     if num_perm <= 0 or num_perm % 4 or num_perm > 2048:
         raise NotImplementedError(f'minhash_num_perm must be a multiple of 4 in [4, 2048], got {num_perm}')
@@ -263,10 +283,10 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
     hub_threshold = HUB_THRESHOLD if hub_threshold is None else hub_threshold
     rowptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=device)
     col = torch.empty(max(E, 1), dtype=torch.int32, device=device)
-    flags = torch.zeros(2, dtype=torch.int64, device=device)  # [0] = n_self (written by the kernel), [1] = error flag | hub count
+    flags = torch.empty(2, dtype=torch.int64, device=device)  # [0] = n_self, [1] = hub count (both cleared by the kernels)
     n_self_dev = flags[0:1]
-    small = flags[1:2].view(torch.int32)
-    err, hub_count = small[0:1], small[1:2]
+    hub_count = flags[1:2].view(torch.int32)[0:1]
+    err = _error_flag(device)
     hub_rows = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=device)
     ws_bytes = lib.ss_csr_workspace_bytes(num_nodes, E)
     if ws_bytes == 0:
@@ -276,7 +296,7 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
         _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(n_self_dev),
                                        hub_threshold, _ptr(hub_rows), _ptr(hub_count), _ptr(err), _ptr(ws), ws_bytes,
                                        _stream(device)), 'ss_csr_build')
-    if check and int(err.item()):
+    if check and _take_error(device):
         raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
     return CsrGraph(rowptr, col, num_nodes, n_self_dev, err, hub_rows, hub_count, hub_threshold)
 
@@ -570,7 +590,7 @@ class ElphHashes(object):
         nf = h * (h + 2)
         out = torch.empty((B, nf), dtype=torch.float32, device=device)
         dbg = None
-        err = torch.zeros(1, dtype=torch.int32, device=device)
+        err = _error_flag(device)
         if want_debug:
             dbg = {'match': torch.empty((B, h, h), dtype=torch.int32, device=device),
                    'zeros': torch.empty((B, h, h), dtype=torch.int32, device=device),
@@ -583,7 +603,7 @@ class ElphHashes(object):
                 _ptr(lk), B, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0), byref(params.struct), flags, _ptr(out),
                 _ptr(dbg['match']) if dbg else None, _ptr(dbg['zeros']) if dbg else None,
                 _ptr(dbg['inter']) if dbg else None, _ptr(err), _stream(device)), 'ss_pair_features')
-        if self.strict_bounds and B > 0 and int(err.item()):
+        if self.strict_bounds and B > 0 and _take_error(device):
             raise IndexError(f'links refer to nodes outside [-{N}, {N})')
         return out, dbg
 
