@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
         my_hs = (l == c) ? hs[c] : my_hs;
     }
     float my_I = 0.0f;
-    const int my_match = my_mz >> 20, my_zeros = my_mz & 0xFFFFF;
+    const int my_match = (int)((uint32_t)my_mz >> 20), my_zeros = my_mz & 0xFFFFF;  // P <= 2048: the packed word uses all 32 bits
     if (l < NC) {
         const float jac = (float)my_match / (float)P;
         my_I = jac * hll_estimate(est, my_zeros, my_hs);

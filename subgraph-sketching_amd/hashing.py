@@ -13,6 +13,7 @@ leaves are only materialised if somebody reads them (torch.save does); the kerne
 """
 import logging
 import weakref
+from collections.abc import Mapping
 from ctypes import byref, c_float, c_void_p
 
 import numpy as np
@@ -134,19 +135,20 @@ def linear_counting_table(m):
 # ------------------------------------------------------------------------------------------------
 # sketch containers
 # ------------------------------------------------------------------------------------------------
-class HopSketch(dict):
+class HopSketch(Mapping):
     """{'hll': int8[N, M], 'minhash': int64[N, P]} of one hop, backed by the packed device tables.
 
     `mh_u32` (torch.int32 holding uint32 bit patterns) and `hll_u8` are what the kernels read.  The
     reference-shaped leaves are created on first access, on `home` (the device the reference would have
-    left them on: where edge_index lived)."""
+    left them on: where edge_index lived).  A read-only Mapping rather than a dict subclass so that every way
+    of reading it (indexing, dict(x), {**x}, .items()) goes through the lazy materialisation."""
     _KEYS = ('hll', 'minhash')
 
     def __init__(self, mh_u32, hll_u8, home, make_packed=None):
-        super().__init__({'hll': None, 'minhash': None})
         self._mh_u32 = mh_u32
         self._hll_u8 = hll_u8
         self._make_packed = make_packed  # deferred producer of (mh_u32, hll_u8): hop 0 is only built if somebody reads it
+        self._leaves = {}
         self.home = home
 
     def _ensure_packed(self):
@@ -164,29 +166,22 @@ class HopSketch(dict):
         self._ensure_packed()
         return self._hll_u8
 
-    def _materialise(self, key):
-        val = dict.__getitem__(self, key)
+    def __getitem__(self, key):
+        if key not in self._KEYS:
+            raise KeyError(key)
+        val = self._leaves.get(key)
         if val is None:
-            if key == 'hll':
-                val = self.hll_u8.view(torch.int8)
-            else:
-                val = unpack_minhash(self.mh_u32)
+            val = self.hll_u8.view(torch.int8) if key == 'hll' else unpack_minhash(self.mh_u32)
             if val.device != self.home:
                 val = val.to(self.home)
-            dict.__setitem__(self, key, val)
+            self._leaves[key] = val
         return val
 
-    def __getitem__(self, key):
-        return self._materialise(key) if key in self._KEYS else dict.__getitem__(self, key)
+    def __iter__(self):
+        return iter(self._KEYS)
 
-    def get(self, key, default=None):
-        return self[key] if key in self else default
-
-    def values(self):
-        return [self[k] for k in self.keys()]
-
-    def items(self):
-        return [(k, self[k]) for k in self.keys()]
+    def __len__(self):
+        return len(self._KEYS)
 
     def __reduce__(self):  # pickles (torch.save) as the reference's plain dict of tensors
         return (dict, (dict(self.items()),))
