@@ -108,6 +108,31 @@ def cpu_baseline(ei, links):
                       f'not the torch/PyG code itself'}, feats
 
 
+def cpu_baseline_reference_style(ei, links):
+    """the reference's dataflow in stock torch CPU ops (oracle/torch_refstyle.py): materialised per-edge messages +
+    scatter-amax, int64 MinHash, h^2 x 4 row gathers, argsort-based bias lookup.  Bounded sample: ONE propagation hop
+    (both sketches + its hll_count) is timed and the build extrapolated to h hops; the query of one batch is timed fully."""
+    import subgraph_sketching_amd as ssa
+    from oracle import oracle, torch_refstyle as tr
+    t = ssa.hll_tables.load(HLL_P)
+    raw, bias = torch.tensor(t.raw_estimate, dtype=torch.float), torch.tensor(t.bias, dtype=torch.float)
+    threads = min(16, os.cpu_count())  # measured best on the 256-core GPU host (8: 3.5 s/hop, 16: 2.5, 32: 3.0, 128: 6.0)
+    torch.set_num_threads(threads)
+    mh0 = torch.from_numpy(oracle.minhash_init(N_NODES, P).astype(np.int64))
+    hll0 = torch.from_numpy(oracle.hll_init(N_NODES, HLL_P).view(np.int8))
+    t0 = time.perf_counter()
+    tables, cards = tr.build_tables(N_NODES, torch.from_numpy(ei), H, mh0, hll0, HLL_P, t.alpha, t.threshold, raw, bias, hops_to_run=1)
+    t_hop = time.perf_counter() - t0
+    for k in range(2, H + 1):  # untimed stand-ins so the query touches h distinct tables of realistic content
+        tables[k] = tables[1]
+    t0 = time.perf_counter()
+    tr.pair_intersections(torch.from_numpy(links), tables, H, P, HLL_P, t.alpha, t.threshold, raw, bias)
+    t_query = time.perf_counter() - t0
+    return {'value': BATCH / (H * t_hop + t_query), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+            'sample': f'reference-style torch CPU ops: 1 of {H} hops timed ({t_hop:.2f} s, build extrapolated to {H * t_hop:.2f} s) + '
+                      f'{BATCH}-pair query ({t_query:.3f} s); torch threads = {torch.get_num_threads()}'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -254,6 +279,8 @@ def main():
         diff = float(np.abs(feats.cpu().numpy() - ofeat).max())
         out['cpu_baseline']['max_abs_feature_diff_vs_gpu'] = diff
         out['speedup_vs_cpu_baseline'] = out['value'] / base['value']
+        if a.config == 'collab':
+            out['cpu_baseline_reference_style'] = cpu_baseline_reference_style(ei_np, links_np)
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:

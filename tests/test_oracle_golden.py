@@ -168,3 +168,29 @@ def test_uniform3000_reaches_bias_branch(regenerated_tables, h):
     ref = g[f'feat_h{h}']
     # features are differences of numbers up to ~3000: absolute tolerance scaled to the operands
     np.testing.assert_allclose(f, ref, rtol=RTOL, atol=1e-5 * float(np.abs(g['cards']).max()) * 4)
+
+
+def test_reference_style_torch_path_matches_oracle(regenerated_tables):
+    """the second CPU baseline of bench.py (stock torch ops, reference dataflow) computes the same things as the oracle"""
+    import torch
+    from oracle import torch_refstyle as tr
+    t = regenerated_tables[8]
+    prm = _prm(regenerated_tables, 8)
+    n = 3000
+    rng = np.random.RandomState(1)
+    e = rng.randint(0, n, size=(2, 12000)).astype(np.int64)
+    ei = np.concatenate([e, e[::-1]], axis=1)
+    otab, ocards = oracle.build_hash_tables(n, ei, 2, 128, prm)
+    raw, bias = torch.tensor(t.raw_estimate, dtype=torch.float), torch.tensor(t.bias, dtype=torch.float)
+    tabs, cards = tr.build_tables(n, torch.from_numpy(ei), 2, torch.from_numpy(otab[0]['minhash'].astype(np.int64)),
+                                  torch.from_numpy(otab[0]['hll'].view(np.int8)), 8, t.alpha, t.threshold, raw, bias)
+    for k in (1, 2):
+        assert np.array_equal(tabs[k]['minhash'].numpy().astype(np.uint32), otab[k]['minhash'])
+        assert np.array_equal(tabs[k]['hll'].numpy().view(np.uint8), otab[k]['hll'])
+    np.testing.assert_allclose(cards.numpy(), ocards, rtol=RTOL, atol=ATOL)
+    links = rng.randint(0, n, size=(500, 2)).astype(np.int64)
+    _, dbg = oracle.pair_features(links, otab, ocards, 2, prm, debug=True)
+    inter = tr.pair_intersections(torch.from_numpy(links), tabs, 2, 128, 8, t.alpha, t.threshold, raw, bias)
+    for k1 in (1, 2):
+        for k2 in (1, 2):
+            np.testing.assert_allclose(inter[(k1, k2)].numpy(), dbg['inter'][:, k1 - 1, k2 - 1], rtol=RTOL, atol=ATOL)
