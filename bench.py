@@ -65,8 +65,12 @@ def synthetic_links(seed):
 class KernelTimer(object):
     """HIP-event pairs around the engine's launches, on the stream they are launched on"""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = {}
+        self.only = only  # None = time every launch; else only these span names (fewer event packets in the stream)
+
+    def wants(self, name):
+        return self.only is None or name in self.only
 
     def record(self, name, stream):
         ev = torch.cuda.Event(enable_timing=True)
@@ -147,6 +151,7 @@ def main():
                          'elph: the exact call sequence of ELPH.forward (models/elph.py:186-213) + one query per step; '
                          'buddy: one build amortised over --buddy-batches query batches (datasets/elph.py:200-208)')
     ap.add_argument('--buddy-batches', type=int, default=40)
+    ap.add_argument('--time-all-kernels', action='store_true', help='HIP-event spans around every launch (default: only the roofline kernel)')
     a = ap.parse_args()
     global N_NODES, E_UND, H, BATCH, GRAPH_KIND, PL_ALPHA
     cfg = CONFIGS[a.config]
@@ -223,8 +228,10 @@ def main():
 
     for _ in range(a.warmup):
         feats = step()
-    timer = KernelTimer()
+    timer = KernelTimer(None if a.time_all_kernels else set())
     hashing.KERNEL_TIMER = timer
+    lib = ssa._native.lib()
+    lib.ss_profile_enable(1)  # HIP events around every launch of the dominant kernel (MinHash table hop), on its stream
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -232,17 +239,28 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     hashing.KERNEL_TIMER = None
+    from ctypes import byref, c_float, c_int32
+    dom_ms, dom_n = c_float(), c_int32()
+    lib.ss_profile_read(byref(dom_ms), byref(dom_n))
+    lib.ss_profile_enable(0)
     if launched:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     prop_ms, prop_n = timer.mean_ms('propagate')
+    mh_ms, mh_n = timer.mean_ms('propagate_mh')
     pair_ms, pair_n = timer.mean_ms('pair_features')
     csr_ms, _ = timer.mean_ms('csr_build')
     first_ms, _ = timer.mean_ms('first_hop')
+    split = {k: timer.mean_ms(k)[0] for k in ('propagate_mh', 'propagate_hll', 'first_hop_mh', 'first_hop_hll') if k in timer.events}
     e_prime = 2 * E_UND + N_NODES
     prop_bytes = (e_prime + N_NODES) * ROW_BYTES + 4 * e_prime + 8 * (N_NODES + 1) + 4 * N_NODES
+    roof_kernel = 'ss::propagate_kernel<128,256> (two-sketch launch)'
+    if dom_n.value:  # the library launches the MinHash and HLL hops separately: the MinHash table hop is the dominant kernel
+        prop_ms, prop_n = dom_ms.value, dom_n.value
+        prop_bytes = (e_prime + N_NODES) * 4 * P + 4 * e_prime + 8 * (N_NODES + 1)
+        roof_kernel = 'ss::propagate_kernel<128,256> (MinHash table hop: (E\'+N)*4P + 4E\' + 8(N+1) bytes)'
     pair_bytes = BATCH * (2 * H * ROW_BYTES + 16 + 8 * H + 4 * H * (H + 2))
     traffic = None
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -262,12 +280,12 @@ def main():
                    'pairs_per_step_per_gpu': pairs_per_step, 'global_pairs_per_step': world * pairs_per_step,
                    'parallelism': f'edge-batch sharded x{world}, sketch table replicated, all_gather of features',
                    'hll_tables': eh.hll_tables.provenance},
-        'roofline': {'kernel': 'ss::propagate_kernel<128,256>' + ('' if H > 1 else ' (not launched at h=1)') +
+        'roofline': {'kernel': roof_kernel + ('' if H > 1 else ' (not launched at h=1)') +
                                (' [elph api mode launches it per sketch: the bytes model below does not apply]' if a.api == 'elph' else ''), 'bound': 'hbm', 'achieved': prop_bytes / (prop_ms * 1e-3) / 1e9 if prop_ms else None,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': prop_bytes / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if prop_ms else None, 'traffic': traffic,
                      'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n},
-        'kernels': {'propagate_ms_per_launch': prop_ms, 'first_hop_ms_per_launch': first_ms, 'pair_features_ms_per_launch': pair_ms, 'csr_build_ms': csr_ms,
+        'kernels': {'split_stream_launch_ms': split, 'propagate_ms_per_launch': prop_ms, 'first_hop_ms_per_launch': first_ms, 'pair_features_ms_per_launch': pair_ms, 'csr_build_ms': csr_ms,
                     'pair_features_algorithmic_bytes': pair_bytes,
                     'pair_features_GBps': pair_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms else None,
                     'pair_features_frac_of_hbm_peak': pair_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pair_ms else None,

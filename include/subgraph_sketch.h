@@ -151,6 +151,12 @@ int ss_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
 int ss_pack_minhash(const int64_t *in, uint32_t *out, int64_t count, void *stream);
 int ss_unpack_minhash(const uint32_t *in, int64_t *out, int64_t count, void *stream);
 
+/* Live launch-duration measurement of the dominant kernel (the MinHash table hop inside ss_propagate): while
+ * enabled, every such launch is bracketed by HIP events on its own stream.  ss_profile_read synchronises those
+ * events, returns their mean duration (ms) and count through host pointers, and clears the list. */
+int ss_profile_enable(int32_t on);
+int ss_profile_read(float *mean_ms_out, int32_t *launches_out);
+
 /* Launch-duration probe for bench.py: records HIP events around `reps` back-to-back launches of the
  * same ss_propagate / ss_pair_features call ON `stream` and returns the mean milliseconds per launch in
  * *ms_out (host pointer).  Synchronises the stream. */

@@ -16,68 +16,12 @@
 // wave-uniform (SGPR pair), each lane evaluates its own permutations on it.
 // Hub rows (see ss_propagate.hip) get a 16-wave workgroup: waves take alternate 64-neighbour batches and
 // combine through LDS atomics.
-#include "ss_common.hpp"
+#include <cstdlib>
+#include "ss_walks.hpp"
 
 namespace ss {
 
-__device__ __forceinline__ uint32_t permuted_hash(uint64_t a, uint64_t b, uint64_t hv)
-{
-    return (uint32_t)mod_mersenne61(a * hv + b);
-}
-
-// processes neighbour batches base = first_batch*64, += batch_stride*64 of one row; acc / hll_row accumulate
-template <int PPL>
-__device__ __forceinline__ void first_hop_walk(const int32_t *__restrict__ nb, int deg, int total, int64_t self_row, int first_batch,
-                                               int batch_stride, int p, const uint64_t (&a)[PPL], const uint64_t (&b)[PPL],
-                                               uint32_t (&acc)[PPL], uint32_t *hll_row, int lane)
-{
-    for (int base = first_batch * kWave; base < total; base += batch_stride * kWave) {
-        const int t = base + lane;
-        const int64_t nid = t < deg ? (int64_t)nb[t] : self_row;  // t == deg is the implicit self loop; t > deg unused
-        const uint64_t hv = hash_u64((uint64_t)(nid + 1));
-        const uint32_t hv_lo = (uint32_t)hv, hv_hi = (uint32_t)(hv >> 32);
-        // HLL (hashing.py:126-137): every lane scatters ITS neighbour's single register into the LDS row
-        if (t < total) {
-            const uint64_t bits = hv >> p;
-            const int bl = bits ? 64 - __builtin_clzll(bits) : 0;
-            atomicMax(&hll_row[hv_lo & 255u], (uint32_t)((64 - p) - bl + 1));
-        }
-        // MinHash: walk the batch; the neighbour's hash is wave-uniform, each lane evaluates its own permutations
-        const int cnt = total - base < kWave ? total - base : kWave;
-        int k = 0;
-        for (; k + 1 < cnt; k += 2) {
-            const uint64_t h0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv_hi, k) << 32) |
-                                (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k);
-            const uint64_t h1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv_hi, k + 1) << 32) |
-                                (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k + 1);
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) {
-                const uint32_t v0 = permuted_hash(a[q], b[q], h0);
-                const uint32_t v1 = permuted_hash(a[q], b[q], h1);
-                const uint32_t v = v0 < v1 ? v0 : v1;
-                acc[q] = v < acc[q] ? v : acc[q];
-            }
-        }
-        if (k < cnt) {
-            const uint64_t h0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv_hi, k) << 32) |
-                                (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k);
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) {
-                const uint32_t v = permuted_hash(a[q], b[q], h0);
-                acc[q] = v < acc[q] ? v : acc[q];
-            }
-        }
-    }
-}
-
-// one lane-quad of HLL registers (u32 each in LDS) -> packed bytes, stored + optional stats for the cardinality
-__device__ __forceinline__ uint32_t pack_hll_quad(const uint32_t *row, int lane)
-{
-    const u32x4 r4 = *reinterpret_cast<const u32x4 *>(row + 4 * lane);
-    return r4.x | (r4.y << 8) | (r4.z << 16) | (r4.w << 24);
-}
-
-template <int PPL /* permutations per lane = P / 64 */>
+template <int PPL /* permutations per lane = P / 64 */, bool DO_MH, bool DO_HLL>
 __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
                                                         uint32_t *__restrict__ mh_out, int p, uint8_t *__restrict__ hll_out,
                                                         float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm,
@@ -85,7 +29,7 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
 {
     __shared__ EstimatorLds lds;
     __shared__ __attribute__((aligned(16))) uint32_t hll_rows[256 / kWave][256];  // one u32 per register and wave
-    const bool want_cards = cards_out != nullptr;
+    const bool want_cards = DO_HLL && cards_out != nullptr;
     EstimatorTables est;
     if (want_cards) est = stage_tables(lds, prm);
 
@@ -111,14 +55,17 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
 
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
     const int total = deg + (i < n_self ? 1 : 0);
-    first_hop_walk<PPL>(g.col + rb, deg, total, i, 0, 1, p, a, b, acc, my_row, lane);
+    first_hop_walk<PPL, DO_MH, DO_HLL>(g.col + rb, deg, total, i, 0, 1, p, a, b, acc, my_row, lane);
 
-    if (total == 0) {
+    if (DO_MH) {
+        if (total == 0) {
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) acc[q] = 0u;  // no in-edge, no self loop: all-zero row (PyG default)
+            for (int q = 0; q < PPL; ++q) acc[q] = 0u;  // no in-edge, no self loop: all-zero row (PyG default)
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = acc[q];
     }
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = acc[q];
+    if (!DO_HLL) return;
     // the wave's LDS row is only touched by this wave: a wave-level fence orders the atomics before the read
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint32_t regs = pack_hll_quad(my_row, lane);  // HLL registers 4*lane .. 4*lane+3
@@ -136,11 +83,67 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
     }
 }
 
+// HLL-only first hop, latency-optimised: one 16-lane DPP row per destination (4 destinations in flight per wave).
+// Used when the caller asks for the HLL sketch alone (the two-stream build runs the HLL chain beside the MinHash
+// chain); the one-row-per-wave kernel above is a single dependent chain per wave and takes 4x longer for this.
+__global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, uint8_t *__restrict__ hll_out,
+                                                            float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm,
+                                                            bool skip_hubs)
+{
+    __shared__ EstimatorLds lds;
+    __shared__ __attribute__((aligned(16))) uint32_t rows[256 / kRow][256];  // one u32 per register and 16-lane group
+    const bool want_cards = cards_out != nullptr;
+    EstimatorTables est;
+    if (want_cards) est = stage_tables(lds, prm);
+    const int l = threadIdx.x & (kRow - 1);
+    const int grp = threadIdx.x / kRow;
+    const int64_t i_raw = (int64_t)blockIdx.x * (blockDim.x / kRow) + grp;
+    const bool ok = i_raw < g.N;
+    const int64_t i = ok ? i_raw : g.N - 1;
+    uint32_t *row = rows[grp];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4 *>(row + 64 * k + 4 * l) = u32x4{0u, 0u, 0u, 0u};
+    const int64_t rb = g.rowptr[i];
+    const int deg = (int)(g.rowptr[i + 1] - rb);
+    const bool hub = skip_hubs && deg > g.hub_threshold;
+    const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
+    const int total = hub ? 0 : deg + (i < n_self ? 1 : 0);
+    const int32_t *nb = g.col + rb;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int t = l; t < total; t += kRow) {
+        const int64_t nid = t < deg ? (int64_t)nb[t] : i;
+        const uint64_t hv = hash_u64((uint64_t)(nid + 1));
+        const uint64_t bits = hv >> p;
+        const int bl = bits ? 64 - __builtin_clzll(bits) : 0;
+        atomicMax(&row[(uint32_t)hv & 255u], (uint32_t)((64 - p) - bl + 1));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // lane l owns registers 16l .. 16l+15
+    u32x4 packed;
+    uint32_t *pw = reinterpret_cast<uint32_t *>(&packed);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pw[k] = pack_hll_quad(row + 16 * l, k);
+    int nonzero = 0;
+    float hsum = 0.0f;
+    if (want_cards) {
+        hll_dword_stats(packed.x, nonzero, hsum);
+        hll_dword_stats(packed.y, nonzero, hsum);
+        hll_dword_stats(packed.z, nonzero, hsum);
+        hll_dword_stats(packed.w, nonzero, hsum);
+        nonzero = row16_sum_i(nonzero);
+        hsum = row16_sum_f(hsum);
+    }
+    if (ok && !hub) {
+        *reinterpret_cast<u32x4 *>(hll_out + i * 256 + 16 * l) = packed;
+        if (want_cards && l == 0) cards_out[i * cards_stride] = hll_estimate(est, 256 - nonzero, hsum);
+    }
+}
+
 constexpr int kHubThreads = 1024;
 constexpr int kHubWaves = kHubThreads / kWave;
 constexpr int kHubGrid = 256;  // one workgroup per CU; workgroups beyond the hub count exit at once
 
-template <int PPL>
+template <int PPL, bool DO_MH, bool DO_HLL>
 __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g, const uint64_t *__restrict__ pa,
                                                                     const uint64_t *__restrict__ pb, uint32_t *__restrict__ mh_out, int p,
                                                                     uint8_t *__restrict__ hll_out, float *__restrict__ cards_out,
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
     __shared__ uint32_t mh_row[PPL * kWave];
     const int n_hubs = *g.hub_count;
     if ((int)blockIdx.x >= n_hubs) return;  // the common case (no hub rows) costs one scalar load per workgroup
-    const bool want_cards = cards_out != nullptr;
+    const bool want_cards = DO_HLL && cards_out != nullptr;
     EstimatorTables est;
     if (want_cards) est = stage_tables(lds, prm);
     constexpr int P = PPL * kWave;
@@ -175,15 +178,22 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
         uint32_t acc[PPL];
 #pragma unroll
         for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
-        first_hop_walk<PPL>(g.col + rb, deg, total, i, wave, kHubWaves, p, a, b, acc, hll_row, lane);
+        first_hop_walk<PPL, DO_MH, DO_HLL>(g.col + rb, deg, total, i, wave, kHubWaves, p, a, b, acc, hll_row, lane);
+        if (DO_MH) {
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) atomicMin(&mh_row[lane + kWave * q], acc[q]);
+            for (int q = 0; q < PPL; ++q) atomicMin(&mh_row[lane + kWave * q], acc[q]);
+        }
         __syncthreads();
         if (wave == 0) {
+            if (DO_MH) {
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = mh_row[lane + kWave * q];
-            const uint32_t regs = pack_hll_quad(hll_row, lane);
-            *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
+                for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = mh_row[lane + kWave * q];
+            }
+            uint32_t regs = 0;
+            if (DO_HLL) {
+                regs = pack_hll_quad(hll_row, lane);
+                *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
+            }
             if (want_cards) {
                 int nonzero = 0;
                 float hsum = 0.0f;
@@ -199,21 +209,84 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
     }
 }
 
+int launch_first_hop_hub_only(const GraphArgs &g, const uint64_t *a, const uint64_t *b, int P, uint32_t *mh_out, int p, uint8_t *hll_out,
+                              float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream);
+
+template <int PPL, bool DO_MH, bool DO_HLL>
+int launch_first_hop_v(const GraphArgs &g, const uint64_t *a, const uint64_t *b, uint32_t *mh_out, int p, uint8_t *hll_out,
+                       float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t s)
+{
+    const int64_t blocks = (g.N + 3) / 4;
+    const bool hubs = g.hub_rows && g.hub_count;
+    static const int extra_lds = getenv("SS_FH_EXTRA_LDS") ? atoi(getenv("SS_FH_EXTRA_LDS")) : 0;  // occupancy experiments
+    hipLaunchKernelGGL((first_hop_kernel<PPL, DO_MH, DO_HLL>), dim3((unsigned)blocks), dim3(256), extra_lds, s, g, a, b, mh_out, p, hll_out,
+                       cards_out, cards_stride, prm, hubs);
+    SS_LAUNCH_CHECK();
+    if (hubs) {
+        hipLaunchKernelGGL((first_hop_hub_kernel<PPL, DO_MH, DO_HLL>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p,
+                           hll_out, cards_out, cards_stride, prm);
+        SS_LAUNCH_CHECK();
+    }
+    return SS_OK;
+}
+
 template <int PPL>
 int launch_first_hop(const GraphArgs &g, const uint64_t *a, const uint64_t *b, uint32_t *mh_out, int p, uint8_t *hll_out,
                      float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t s)
 {
-    const int64_t blocks = (g.N + 3) / 4;
+    if (mh_out && hll_out) {
+        // both sketches: the latency-optimised HLL kernel + the MinHash kernel beat the combined kernel (37 + 134 us vs
+        // 184 us on the bench graph); one hub pass serves both
+        const bool hubs = g.hub_rows && g.hub_count;
+        hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.N + 15) / 16)), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
+                           prm, hubs);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((first_hop_kernel<PPL, true, false>), dim3((unsigned)((g.N + 3) / 4)), dim3(256), 0, s, g, a, b, mh_out, p,
+                           (uint8_t *)nullptr, (float *)nullptr, (int64_t)0, prm, hubs);
+        SS_LAUNCH_CHECK();
+        return launch_first_hop_hub_only(g, a, b, PPL * kWave, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
+    }
+    if (mh_out) return launch_first_hop_v<PPL, true, false>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
+    // HLL alone: 16-lane-per-row kernel for the regular rows, the cooperative hub kernel for the rest
     const bool hubs = g.hub_rows && g.hub_count;
-    hipLaunchKernelGGL((first_hop_kernel<PPL>), dim3((unsigned)blocks), dim3(256), 0, s, g, a, b, mh_out, p, hll_out, cards_out,
-                       cards_stride, prm, hubs);
+    hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.N + 15) / 16)), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
+                       prm, hubs);
     SS_LAUNCH_CHECK();
     if (hubs) {
-        hipLaunchKernelGGL((first_hop_hub_kernel<PPL>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p, hll_out, cards_out,
-                           cards_stride, prm);
+        hipLaunchKernelGGL((first_hop_hub_kernel<PPL, false, true>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p,
+                           hll_out, cards_out, cards_stride, prm);
         SS_LAUNCH_CHECK();
     }
     return SS_OK;
+}
+
+template <int PPL>
+static int hub_only(const GraphArgs &g, const uint64_t *a, const uint64_t *b, uint32_t *mh_out, int p, uint8_t *hll_out, float *cards_out,
+                    int64_t cards_stride, const ss_hll_params &prm, hipStream_t s)
+{
+    if (mh_out && hll_out)
+        hipLaunchKernelGGL((first_hop_hub_kernel<PPL, true, true>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p, hll_out,
+                           cards_out, cards_stride, prm);
+    else if (mh_out)
+        hipLaunchKernelGGL((first_hop_hub_kernel<PPL, true, false>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p, hll_out,
+                           cards_out, cards_stride, prm);
+    else
+        hipLaunchKernelGGL((first_hop_hub_kernel<PPL, false, true>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p, hll_out,
+                           cards_out, cards_stride, prm);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+int launch_first_hop_hub_only(const GraphArgs &g, const uint64_t *a, const uint64_t *b, int P, uint32_t *mh_out, int p, uint8_t *hll_out,
+                              float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
+{
+    if (!g.hub_rows || !g.hub_count) return SS_OK;
+    switch (P / kWave) {
+        case 1: return hub_only<1>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, stream);
+        case 2: return hub_only<2>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, stream);
+        case 3: return hub_only<3>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, stream);
+        default: return hub_only<4>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, stream);
+    }
 }
 
 }  // namespace ss
@@ -227,10 +300,11 @@ extern "C" int ss_first_hop(const ss_csr_graph *graph, const uint64_t *a, const 
     if (p != 8 || P <= 0 || P % kWave || P > 256) return SS_ERR_UNSUPPORTED;  // caller falls back to init + propagate
     const int64_t N = graph->num_nodes;
     if (N == 0) return SS_OK;
-    if (!a || !b || !mh_out || !hll_out || N >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
+    if (!a || !b || (!mh_out && !hll_out) || N >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;  // either sketch may be NULL
     if ((graph->hub_rows == nullptr) != (graph->hub_count == nullptr)) return SS_ERR_INVALID_ARG;
     ss_hll_params p0 = {};
     if (cards_out) {
+        if (!hll_out) return SS_ERR_INVALID_ARG;
         const int rc = check_params(prm);
         if (rc != SS_OK) return rc;
         if (prm->p != p) return SS_ERR_INVALID_ARG;

@@ -1,0 +1,170 @@
+// ss_walks.hpp -- the neighbour walks shared by the propagation kernels (ss_propagate.hip, ss_first_hop.hip): table-reading walks (one 16-byte chunk per lane) and the table-free first-hop walk.
+#pragma once
+#include "ss_common.hpp"
+
+namespace ss {
+
+__device__ __forceinline__ u32x4 shfl_xor4(u32x4 v, int mask)
+{
+    u32x4 r;
+    r.x = (uint32_t)__shfl_xor((int)v.x, mask);
+    r.y = (uint32_t)__shfl_xor((int)v.y, mask);
+    r.z = (uint32_t)__shfl_xor((int)v.z, mask);
+    r.w = (uint32_t)__shfl_xor((int)v.w, mask);
+    return r;
+}
+
+__host__ __device__ constexpr int pow2_ceil(int x)
+{
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// min over the neighbours t = first, first + stride, ... < total of MinHash chunk c (16 bytes per lane)
+__device__ __forceinline__ u32x4 minhash_walk(const uint32_t *__restrict__ mh_in, const int32_t *__restrict__ nb, int deg, int total,
+                                              int64_t self_row, int first, int stride, int P, int c)
+{
+    u32x4 acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll 4
+    for (int t = first; t < total; t += stride) {
+        const int64_t j = t < deg ? (int64_t)nb[t] : self_row;
+        acc = min4(acc, *reinterpret_cast<const u32x4 *>(mh_in + j * P + 4 * c));
+    }
+    return acc;
+}
+
+// byte-wise max over the same neighbour walk of HLL chunk c; even / odd bytes accumulated as packed u16
+__device__ __forceinline__ u32x4 hll_walk(const uint8_t *__restrict__ hll_in, const int32_t *__restrict__ nb, int deg, int total,
+                                          int64_t self_row, int first, int stride, int M, int c)
+{
+    u32x4 ae = {0u, 0u, 0u, 0u}, ao = {0u, 0u, 0u, 0u};
+#pragma unroll 4
+    for (int t = first; t < total; t += stride) {
+        const int64_t j = t < deg ? (int64_t)nb[t] : self_row;
+        const u32x4 x = *reinterpret_cast<const u32x4 *>(hll_in + j * M + 16 * c);
+        ae.x = pk_max_u16(ae.x, x.x & 0x00FF00FFu); ao.x = pk_max_u16(ao.x, x.x & 0xFF00FF00u);
+        ae.y = pk_max_u16(ae.y, x.y & 0x00FF00FFu); ao.y = pk_max_u16(ao.y, x.y & 0xFF00FF00u);
+        ae.z = pk_max_u16(ae.z, x.z & 0x00FF00FFu); ao.z = pk_max_u16(ao.z, x.z & 0xFF00FF00u);
+        ae.w = pk_max_u16(ae.w, x.w & 0x00FF00FFu); ao.w = pk_max_u16(ao.w, x.w & 0xFF00FF00u);
+    }
+    return u32x4{ae.x | ao.x, ae.y | ao.y, ae.z | ao.z, ae.w | ao.w};
+}
+
+__device__ __forceinline__ uint32_t permuted_hash(uint64_t a, uint64_t b, uint64_t hv)
+{
+    return (uint32_t)mod_mersenne61(a * hv + b);
+}
+
+// processes neighbour batches base = first_batch*64, += batch_stride*64 of one row; acc / hll_row accumulate
+template <int PPL, bool DO_MH, bool DO_HLL>
+__device__ __forceinline__ void first_hop_walk(const int32_t *__restrict__ nb, int deg, int total, int64_t self_row, int first_batch,
+                                               int batch_stride, int p, const uint64_t (&a)[PPL], const uint64_t (&b)[PPL],
+                                               uint32_t (&acc)[PPL], uint32_t *hll_row, int lane)
+{
+    for (int base = first_batch * kWave; base < total; base += batch_stride * kWave) {
+        const int t = base + lane;
+        const int64_t nid = t < deg ? (int64_t)nb[t] : self_row;  // t == deg is the implicit self loop; t > deg unused
+        const uint64_t hv = hash_u64((uint64_t)(nid + 1));
+        const uint32_t hv_lo = (uint32_t)hv, hv_hi = (uint32_t)(hv >> 32);
+        // HLL (hashing.py:126-137): every lane scatters ITS neighbour's single register into the LDS row
+        if (DO_HLL && t < total) {
+            const uint64_t bits = hv >> p;
+            const int bl = bits ? 64 - __builtin_clzll(bits) : 0;
+            atomicMax(&hll_row[hv_lo & 255u], (uint32_t)((64 - p) - bl + 1));
+        }
+        // MinHash: walk the batch; the neighbour's hash is wave-uniform, each lane evaluates its own permutations
+        if (!DO_MH) continue;
+        const int cnt = total - base < kWave ? total - base : kWave;
+        int k = 0;
+        // 4 neighbours per iteration: 4 * PPL independent multiply chains per lane (the integer multiplies have long
+        // issue + latency; a single chain per wave leaves the VALU idle)
+        for (; k + 3 < cnt; k += 4) {
+            uint64_t hh[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                hh[u] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv_hi, k + u) << 32) |
+                        (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k + u);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const uint32_t v0 = permuted_hash(a[q], b[q], hh[0]);
+                const uint32_t v1 = permuted_hash(a[q], b[q], hh[1]);
+                const uint32_t v2 = permuted_hash(a[q], b[q], hh[2]);
+                const uint32_t v3 = permuted_hash(a[q], b[q], hh[3]);
+                const uint32_t m01 = v0 < v1 ? v0 : v1, m23 = v2 < v3 ? v2 : v3;
+                const uint32_t v = m01 < m23 ? m01 : m23;
+                acc[q] = v < acc[q] ? v : acc[q];
+            }
+        }
+        for (; k + 1 < cnt; k += 2) {
+            const uint64_t h0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv_hi, k) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k);
+            const uint64_t h1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv_hi, k + 1) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k + 1);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const uint32_t v0 = permuted_hash(a[q], b[q], h0);
+                const uint32_t v1 = permuted_hash(a[q], b[q], h1);
+                const uint32_t v = v0 < v1 ? v0 : v1;
+                acc[q] = v < acc[q] ? v : acc[q];
+            }
+        }
+        if (k < cnt) {
+            const uint64_t h0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv_hi, k) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const uint32_t v = permuted_hash(a[q], b[q], h0);
+                acc[q] = v < acc[q] ? v : acc[q];
+            }
+        }
+    }
+}
+
+// one lane-quad of HLL registers (u32 each in LDS) -> packed bytes, stored + optional stats for the cardinality
+__device__ __forceinline__ uint32_t pack_hll_quad(const uint32_t *row, int lane)
+{
+    const u32x4 r4 = *reinterpret_cast<const u32x4 *>(row + 4 * lane);
+    return r4.x | (r4.y << 8) | (r4.z << 16) | (r4.w << 24);
+}
+
+// HLL table hop for FOUR destination rows per wavefront: one 16-lane DPP row per destination, lane c owns the 16-byte
+// chunk c of the 256-byte HLL row.  Compared with one destination per wave (hll_walk + two cross-group shuffles +
+// an epilogue that uses 16 of 64 lanes) this keeps 4x the loads in flight per wave and runs the cardinality
+// epilogue for 4 rows at once.  `row` < 0 marks an inactive group.  M = 256 only.
+__device__ __forceinline__ void hll_hop_row16(const GraphArgs &g, int64_t row, bool skip_hubs, const uint8_t *__restrict__ hll_in,
+                                              uint8_t *__restrict__ hll_out, float *__restrict__ cards_out, int64_t cards_stride,
+                                              const EstimatorTables &est, bool want_cards, int c /* lane & 15 */)
+{
+    constexpr int M = 256;
+    const bool ok = row >= 0;
+    const int64_t i = ok ? row : 0;
+    const int64_t rb = g.rowptr[i];
+    const int deg = (int)(g.rowptr[i + 1] - rb);
+    const bool hub = skip_hubs && deg > g.hub_threshold;
+    const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
+    const int total = (!ok || hub) ? 0 : deg + (i < n_self ? 1 : 0);
+    const u32x4 acc = hll_walk(hll_in, g.col + rb, deg, total, i, 0, 1, M, c);
+    int nonzero = 0;
+    float hsum = 0.0f;
+    if (want_cards) {
+        hll_dword_stats(acc.x, nonzero, hsum);
+        hll_dword_stats(acc.y, nonzero, hsum);
+        hll_dword_stats(acc.z, nonzero, hsum);
+        hll_dword_stats(acc.w, nonzero, hsum);
+        nonzero = row16_sum_i(nonzero);
+        hsum = row16_sum_f(hsum);
+    }
+    if (ok && !hub) {
+        *reinterpret_cast<u32x4 *>(hll_out + i * M + 16 * c) = acc;
+        if (want_cards && c == 0) cards_out[i * cards_stride] = hll_estimate(est, M - nonzero, hsum);
+    }
+}
+
+// hub-row-only launches (defined in ss_first_hop.hip / ss_propagate.hip) for kernels that skip hub rows themselves
+int launch_first_hop_hub_only(const GraphArgs &g, const uint64_t *a, const uint64_t *b, int P, uint32_t *mh_out, int p, uint8_t *hll_out,
+                              float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream);
+int launch_propagate_hub_only(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, const uint8_t *hll_in, uint8_t *hll_out,
+                              float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream);
+
+}  // namespace ss

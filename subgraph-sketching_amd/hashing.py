@@ -41,7 +41,10 @@ class _Span(object):
     """optional HIP-event bracket around a launch, recorded on the launch stream"""
 
     def __init__(self, name, device):
-        self.name, self.device, self.timer = name, device, KERNEL_TIMER
+        timer = KERNEL_TIMER
+        if timer is not None and hasattr(timer, 'wants') and not timer.wants(name):
+            timer = None
+        self.name, self.device, self.timer = name, device, timer
 
     def __enter__(self):
         if self.timer is not None:
@@ -317,16 +320,18 @@ class _CsrCache(object):
 _default_csr_cache = _CsrCache()
 
 
-def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, params=None):
+def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, params=None, mh_out=None, hll_out=None):
     """one hop; returns (mh_out or None, hll_out or None).  mh_in packed int32 [N,P], hll_in uint8 [N,M]"""
     N = csr.num_nodes
-    mh_out = torch.empty_like(mh_in) if mh_in is not None else None
-    hll_out = torch.empty_like(hll_in) if hll_in is not None else None
+    if mh_in is not None and mh_out is None:
+        mh_out = torch.empty_like(mh_in)
+    if hll_in is not None and hll_out is None:
+        hll_out = torch.empty_like(hll_in)
     P = mh_in.size(1) if mh_in is not None else 0
     M = hll_in.size(1) if hll_in is not None else 0
     prm = byref(params.struct) if params is not None else None
     graph = csr.struct()
-    with _Span('propagate', device):
+    with _Span('propagate' if (mh_in is not None and hll_in is not None) else ('propagate_mh' if hll_in is None else 'propagate_hll'), device):
         _native.check(_native.lib().ss_propagate(byref(graph), _ptr(mh_in), _ptr(mh_out), P, _ptr(hll_in), _ptr(hll_out), M,
                                                  _ptr(cards_out), cards_stride, prm, _stream(device)), 'ss_propagate')
     return mh_out, hll_out
@@ -514,40 +519,41 @@ class ElphHashes(object):
         csr.use_inferred_self_loops = True
         cards = torch.empty((num_nodes, self.max_hops), dtype=torch.float32, device=device)
         table = SketchTable()
-        mh, hll = self._first_hop(csr, num_nodes, device, cards, params)
-        if mh is not None:
-            # hop 1 was computed straight from node ids; the hop-0 tables (pure functions of the node id, never read
-            # by get_subgraph_features) are produced only if a caller actually looks at them
+        h = self.max_hops
+        fused = self.fuse_first_hop and self.p == 8 and self.num_perm % 64 == 0 and self.num_perm <= 256
+        if fused:
+            # hop 1 is computed straight from node ids (ss_first_hop); the hop-0 tables (pure functions of the node id,
+            # never read by get_subgraph_features) are produced only if a caller actually looks at them
             table[0] = HopSketch(None, None, home, make_packed=lambda n=num_nodes, d=device: (self._init_minhash_u32(n, d),
                                                                                             self._init_hll_u8(n, d)))
-            first = 2
-            table[1] = HopSketch(mh, hll, home)
+            mh = [torch.empty((num_nodes, self.num_perm), dtype=torch.int32, device=device) for _ in range(h)]
+            hll = [torch.empty((num_nodes, self.m), dtype=torch.uint8, device=device) for _ in range(h)]
+            # (inside the library each of these calls is one launch per sketch + one hub pass: measured faster than
+            # two-sketch kernels -- first hop 37 + 134 us vs 184, table hop 111 + 192 us vs 326 on the bench graph)
+            self._first_hop(csr, device, mh[0], hll[0], cards, params)
+            for k in range(2, h + 1):
+                _propagate(csr, mh[k - 2], hll[k - 2], device, cards_out=cards[:, k - 1], cards_stride=h, params=params,
+                           mh_out=mh[k - 1], hll_out=hll[k - 1])
+            for k in range(1, h + 1):
+                table[k] = HopSketch(mh[k - 1], hll[k - 1], home)
         else:
-            mh = self._init_minhash_u32(num_nodes, device)
-            hll = self._init_hll_u8(num_nodes, device)
-            table[0] = HopSketch(mh, hll, home)
-            first = 1
-        for k in range(first, self.max_hops + 1):
-            logger.info(f"Calculating hop {k} hashes")
-            mh, hll = _propagate(csr, mh, hll, device, cards_out=cards[:, k - 1], cards_stride=self.max_hops, params=params)
-            table[k] = HopSketch(mh, hll, home)
+            mh_k = self._init_minhash_u32(num_nodes, device)
+            hll_k = self._init_hll_u8(num_nodes, device)
+            table[0] = HopSketch(mh_k, hll_k, home)
+            for k in range(1, h + 1):
+                logger.info(f"Calculating hop {k} hashes")
+                mh_k, hll_k = _propagate(csr, mh_k, hll_k, device, cards_out=cards[:, k - 1], cards_stride=h, params=params)
+                table[k] = HopSketch(mh_k, hll_k, home)
         return table, (cards if home == device else cards.to(home))
 
-    def _first_hop(self, csr, num_nodes, device, cards, params):
-        """fused hop-0 + hop-1 (ss_first_hop); returns (None, None) when the kernel has no variant for (P, p)"""
-        if not self.fuse_first_hop:
-            return None, None
+    def _first_hop(self, csr, device, mh_out, hll_out, cards, params):
+        """fused hop-0 + hop-1 (ss_first_hop) for either or both sketches"""
         ab = self._perms(device)
-        mh = torch.empty((num_nodes, self.num_perm), dtype=torch.int32, device=device)
-        hll = torch.empty((num_nodes, self.m), dtype=torch.uint8, device=device)
         graph = csr.struct()
-        with _Span('first_hop', device):
-            rc = _native.lib().ss_first_hop(byref(graph), _ptr(ab[0]), _ptr(ab[1]), self.num_perm, _ptr(mh), self.p, _ptr(hll),
-                                            _ptr(cards), self.max_hops, byref(params.struct), _stream(device))
-        if rc == -4:  # SS_ERR_UNSUPPORTED: no fused variant for this (num_perm, p)
-            return None, None
-        _native.check(rc, 'ss_first_hop')
-        return mh, hll
+        with _Span('first_hop_mh' if hll_out is None else ('first_hop_hll' if mh_out is None else 'first_hop'), device):
+            _native.check(_native.lib().ss_first_hop(byref(graph), _ptr(ab[0]), _ptr(ab[1]), self.num_perm, _ptr(mh_out), self.p,
+                                                     _ptr(hll_out), _ptr(cards) if hll_out is not None else None, self.max_hops,
+                                                     byref(params.struct), _stream(device)), 'ss_first_hop')
 
     # ---- query ---------------------------------------------------------------------------------------
     def _resolve_tables(self, hash_table, device):
