@@ -249,11 +249,10 @@ def main():
         elapsed = float(tmax.item())
 
     prop_ms, prop_n = timer.mean_ms('propagate')
-    mh_ms, mh_n = timer.mean_ms('propagate_mh')
+    prop_call_ms = prop_ms
     pair_ms, pair_n = timer.mean_ms('pair_features')
     csr_ms, _ = timer.mean_ms('csr_build')
     first_ms, _ = timer.mean_ms('first_hop')
-    split = {k: timer.mean_ms(k)[0] for k in ('propagate_mh', 'propagate_hll', 'first_hop_mh', 'first_hop_hll') if k in timer.events}
     e_prime = 2 * E_UND + N_NODES
     prop_bytes = (e_prime + N_NODES) * ROW_BYTES + 4 * e_prime + 8 * (N_NODES + 1) + 4 * N_NODES
     roof_kernel = 'ss::propagate_kernel<128,256> (two-sketch launch)'
@@ -284,13 +283,13 @@ def main():
                                (' [elph api mode launches it per sketch: the bytes model below does not apply]' if a.api == 'elph' else ''), 'bound': 'hbm', 'achieved': prop_bytes / (prop_ms * 1e-3) / 1e9 if prop_ms else None,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': prop_bytes / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if prop_ms else None, 'traffic': traffic,
-                     'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n},
-        'kernels': {'split_stream_launch_ms': split, 'propagate_ms_per_launch': prop_ms, 'first_hop_ms_per_launch': first_ms, 'pair_features_ms_per_launch': pair_ms, 'csr_build_ms': csr_ms,
-                    'pair_features_algorithmic_bytes': pair_bytes,
-                    'pair_features_GBps': pair_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms else None,
-                    'pair_features_frac_of_hbm_peak': pair_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pair_ms else None,
-                    'query_only_pairs_per_s': BATCH / (pair_ms * 1e-3) if pair_ms else None},
+                     'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n}
     }
+    if a.time_all_kernels:  # host-side HIP-event spans around every library call (perturbs the step by ~7 %)
+        out['kernels'] = {'propagate_call_ms': prop_call_ms, 'first_hop_call_ms': first_ms, 'pair_features_ms': pair_ms,
+                          'csr_build_ms': csr_ms, 'pair_features_algorithmic_bytes': pair_bytes,
+                          'pair_features_GBps': pair_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms else None,
+                          'query_only_pairs_per_s': BATCH / (pair_ms * 1e-3) if pair_ms else None}
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config in ('collab', 'cora'):
         base, ofeat = cpu_baseline(ei_np, links_np)
         out['cpu_baseline'] = base
