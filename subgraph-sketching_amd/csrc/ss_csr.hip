@@ -8,16 +8,15 @@
 // 1000 edges each way (first version: 0.23 ms for 2.4 M edges, profiles/round1_v1_kernel_stats.csv).
 //
 //   A1 bucket_count   : each block takes a contiguous slice of the edge list, histograms dst >> shift in
-//                       LDS (a bucket = NB consecutive nodes), writes its row of the [blocks x buckets]
-//                       count matrix; also validates ids and reduces max(id)+1 (= self-loop count of
-//                       add_self_loops, hashing.py:148).
+//                       LDS (a bucket = NB = 1024 consecutive nodes; 256..8192 were measured, 1024 is best on
+//                       every shape), writes its column of the bucket-major [buckets x blocks] count matrix.
 //   A2 bucket_offsets : per bucket, exclusive scan over blocks (column of the matrix) + bucket totals.
 //   A3 bucket_bases   : single block, exclusive scan of bucket totals -> bucket base offsets.
-//   A4 bucket_scatter : same slices as A1; LDS cursors seeded with base[bucket] + offset[block][bucket];
-//                       edges are written as (src, dst) int32 pairs grouped by bucket.
+//   A4 bucket_scatter : same slices as A1; LDS cursors seeded with base[bucket] + offset[bucket][block];
+//                       edges are written as (src, dst) int32 pairs grouped by bucket; also validates src and
+//                       reduces max(id)+1 (= self-loop count of add_self_loops, hashing.py:148).
 //   B  bucket_finish  : one block per bucket: LDS histogram over its NB nodes, LDS scan -> rowptr,
 //                       LDS cursors -> col.
-#include <cstdlib>
 #include "ss_common.hpp"
 
 namespace ss {
@@ -41,10 +40,6 @@ struct CsrPlan {
 inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
 {
     int nb = kMinNodesPerBucket, shift = 10;
-    if (const char *env = getenv("SS_CSR_NB_LOG2")) {  // tuning knob (experiments only)
-        const int v = atoi(env);
-        if (v >= 8 && v <= 14) { shift = v; nb = 1 << v; }
-    }
     while ((N + nb - 1) / nb > kMaxBuckets && nb < kMaxNodesPerBucket) { nb <<= 1; ++shift; }
     if ((N + nb - 1) / nb > kMaxBuckets) return false;
     p.shift = shift;

@@ -16,7 +16,6 @@
 // wave-uniform (SGPR pair), each lane evaluates its own permutations on it.
 // Hub rows (see ss_propagate.hip) get a 16-wave workgroup: waves take alternate 64-neighbour batches and
 // combine through LDS atomics.
-#include <cstdlib>
 #include "ss_walks.hpp"
 
 namespace ss {
@@ -218,8 +217,7 @@ int launch_first_hop_v(const GraphArgs &g, const uint64_t *a, const uint64_t *b,
 {
     const int64_t blocks = (g.N + 3) / 4;
     const bool hubs = g.hub_rows && g.hub_count;
-    static const int extra_lds = getenv("SS_FH_EXTRA_LDS") ? atoi(getenv("SS_FH_EXTRA_LDS")) : 0;  // occupancy experiments
-    hipLaunchKernelGGL((first_hop_kernel<PPL, DO_MH, DO_HLL>), dim3((unsigned)blocks), dim3(256), extra_lds, s, g, a, b, mh_out, p, hll_out,
+    hipLaunchKernelGGL((first_hop_kernel<PPL, DO_MH, DO_HLL>), dim3((unsigned)blocks), dim3(256), 0, s, g, a, b, mh_out, p, hll_out,
                        cards_out, cards_stride, prm, hubs);
     SS_LAUNCH_CHECK();
     if (hubs) {
