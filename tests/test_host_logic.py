@@ -137,3 +137,28 @@ def test_unsupported_sizes_raise(ssa):
         ssa.hashing._check_sizes(6, 8)
     with pytest.raises(NotImplementedError):
         ssa.hashing._check_sizes(128, 17)
+
+
+def test_datasketch_tables_are_used_when_importable(ssa, monkeypatch):
+    """with `datasketch` importable its objects are used verbatim (provenance 'datasketch'); simulated here with a
+    stand-in module carrying recognisable values"""
+    import sys
+    import types
+    ds = types.ModuleType('datasketch')
+    const = types.ModuleType('datasketch.hyperloglog_const')
+    const._thresholds = [10, 20, 40, 80, 220, 400, 900, 1800, 3100, 6500, 11500, 20000, 50000, 120000, 350000]
+    const._raw_estimate = [[float(100 + 7 * i) for i in range(80 + k)] for k in range(15)]
+    const._bias = [[float(i % 5) for i in range(80 + k)] for k in range(15)]
+
+    class HyperLogLogPlusPlus(object):
+        def __init__(self, p=8):
+            self.alpha, self.max_rank, self.reg = 0.5, 64 - p, np.zeros(1 << p, dtype=np.int8)
+
+    ds.HyperLogLogPlusPlus, ds.hyperloglog_const = HyperLogLogPlusPlus, const
+    monkeypatch.setitem(sys.modules, 'datasketch', ds)
+    monkeypatch.setitem(sys.modules, 'datasketch.hyperloglog_const', const)
+    t = ssa.hll_tables.load(8)
+    assert t.provenance == 'datasketch' and t.alpha == 0.5 and t.threshold == 220.0 and len(t.raw_estimate) == 84
+    eh = ssa.ElphHashes(_args())
+    assert eh.hll_tables.provenance == 'datasketch' and eh.alpha == 0.5 and eh.estimate_vector.shape == (84,)
+    assert ssa.hll_tables.load(8, prefer='regenerated').provenance == 'regenerated'
