@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
     uint32_t acc[PPL];
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
-        a[q] = pa[lane + kWave * q];
-        b[q] = pb[lane + kWave * q];
+        a[q] = DO_MH ? pa[lane + kWave * q] : 0ULL;
+        b[q] = DO_MH ? pb[lane + kWave * q] : 0ULL;
         acc[q] = 0xFFFFFFFFu;
     }
     uint32_t *my_row = hll_rows[wave];
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
     uint64_t a[PPL], b[PPL];
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
-        a[q] = pa[lane + kWave * q];
-        b[q] = pb[lane + kWave * q];
+        a[q] = DO_MH ? pa[lane + kWave * q] : 0ULL;
+        b[q] = DO_MH ? pb[lane + kWave * q] : 0ULL;
     }
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
     for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
@@ -298,7 +298,7 @@ extern "C" int ss_first_hop(const ss_csr_graph *graph, const uint64_t *a, const 
     if (p != 8 || P <= 0 || P % kWave || P > 256) return SS_ERR_UNSUPPORTED;  // caller falls back to init + propagate
     const int64_t N = graph->num_nodes;
     if (N == 0) return SS_OK;
-    if (!a || !b || (!mh_out && !hll_out) || N >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;  // either sketch may be NULL
+    if ((!mh_out && !hll_out) || (mh_out && (!a || !b)) || N >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;  // either sketch may be NULL; a / b only feed MinHash
     if ((graph->hub_rows == nullptr) != (graph->hub_count == nullptr)) return SS_ERR_INVALID_ARG;
     ss_hll_params p0 = {};
     if (cards_out) {

@@ -213,34 +213,37 @@ def unpack_minhash(x_u32):
     return out
 
 
+def _tag(t, name, twin):
+    """attach a packed twin to a reference-shaped tensor, stamped with the tensor's version counter so that any
+    in-place edit invalidates it"""
+    try:
+        setattr(t, name, (t._version, twin))
+    except Exception:  # pragma: no cover
+        pass
+
+
 def _packed_minhash_of(t, device):
     """packed twin of a reference-shaped int64 MinHash tensor (cached on the tensor object)"""
-    tw = getattr(t, '_ss_u32', None)
-    if tw is not None and tw.device == device and tw.shape == t.shape:
-        return tw
+    tag = getattr(t, '_ss_u32', None)
+    if tag is not None and tag[0] == t._version and tag[1].device == device and tag[1].shape == t.shape:
+        return tag[1]  # still valid: the tensor has not been edited in place since the twin was made
     if t.dtype == torch.int32:
         tw = t.to(device).contiguous()
     else:
         tw = pack_minhash(t, device)
-    try:
-        t._ss_u32 = tw
-    except Exception:  # pragma: no cover
-        pass
+    _tag(t, '_ss_u32', tw)
     return tw
 
 
 def _packed_hll_of(t, device):
-    tw = getattr(t, '_ss_u8', None)
-    if tw is not None and tw.device == device and tw.shape == t.shape:
-        return tw
+    tag = getattr(t, '_ss_u8', None)
+    if tag is not None and tag[0] == t._version and tag[1].device == device and tag[1].shape == t.shape:
+        return tag[1]
     if t.dtype in (torch.int8, torch.uint8):
         tw = t.to(device).contiguous().view(torch.uint8)
     else:
         tw = t.to(device=device, dtype=torch.uint8).contiguous()
-    try:
-        t._ss_u8 = tw
-    except Exception:  # pragma: no cover
-        pass
+    _tag(t, '_ss_u8', tw)
     return tw
 
 
@@ -337,6 +340,27 @@ def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, param
     return mh_out, hll_out
 
 
+def _hop0_marker(x, device):
+    """(perms, p) if x is an unmodified hop-0 tensor produced by initialise_minhash / initialise_hll on `device`"""
+    tag = getattr(x, '_ss_hop0', None)
+    if tag is None or tag[0] != x._version or x.device != device:
+        return None
+    return tag[1], tag[2]
+
+
+def _first_hop_from_ids(csr, device, perms, num_perm, p, mh_out, hll_out):
+    """ss_first_hop for one sketch; returns False when the fused kernel has no variant for (num_perm, p)"""
+    graph = csr.struct()
+    with _Span('first_hop', device):
+        rc = _native.lib().ss_first_hop(byref(graph), _ptr(perms[0]) if perms is not None else None,
+                                        _ptr(perms[1]) if perms is not None else None, num_perm, _ptr(mh_out), p,
+                                        _ptr(hll_out), None, 0, None, _stream(device))
+    if rc == -4:
+        return False
+    _native.check(rc, 'ss_first_hop')
+    return True
+
+
 class MinhashPropagation(object):
     """drop-in for reference hashing.py:28-35: out[i] = min over in-neighbours (edges j -> i) of x[j];
     rows without an in-edge are 0.  x: int64 [N, P] with values in [0, 2^32)."""
@@ -349,9 +373,16 @@ class MinhashPropagation(object):
         _check_sizes(x.size(1), 8)
         device = _compute_device(x, edge_index)
         csr = self._cache.get(edge_index, x.size(0), device)
-        out_u32, _ = _propagate(csr, _packed_minhash_of(x, device), None, device)
+        hop0 = _hop0_marker(x, device)
+        out_u32 = None
+        if hop0 is not None and hop0[0] is not None:
+            out_u32 = torch.empty((x.size(0), x.size(1)), dtype=torch.int32, device=device)
+            if not _first_hop_from_ids(csr, device, hop0[0], x.size(1), hop0[1], out_u32, None):
+                out_u32 = None
+        if out_u32 is None:
+            out_u32, _ = _propagate(csr, _packed_minhash_of(x, device), None, device)
         out = unpack_minhash(out_u32)
-        out._ss_u32 = out_u32
+        _tag(out, '_ss_u32', out_u32)
         return out if x.device == device else out.to(x.device)
 
     __call__ = forward
@@ -370,11 +401,18 @@ class HllPropagation(object):
             raise NotImplementedError(f'HLL rows must have 2^p registers, 4 <= p <= 16, got {M}')
         device = _compute_device(x, edge_index)
         csr = self._cache.get(edge_index, x.size(0), device)
-        _, out_u8 = _propagate(csr, None, _packed_hll_of(x, device), device)
+        hop0 = _hop0_marker(x, device)
+        out_u8 = None
+        if hop0 is not None and hop0[0] is None and M == 256:
+            out_u8 = torch.empty((x.size(0), M), dtype=torch.uint8, device=device)
+            if not _first_hop_from_ids(csr, device, None, 128, hop0[1], None, out_u8):
+                out_u8 = None
+        if out_u8 is None:
+            _, out_u8 = _propagate(csr, None, _packed_hll_of(x, device), device)
         out = out_u8.view(torch.int8) if x.dtype != torch.uint8 else out_u8
         if out.dtype != x.dtype:
             out = out.to(x.dtype)
-        out._ss_u8 = out_u8
+        _tag(out, '_ss_u8', out_u8)
         return out if x.device == device else out.to(x.device)
 
     __call__ = forward
@@ -495,7 +533,10 @@ class ElphHashes(object):
         device = _compute_device()
         packed = self._init_minhash_u32(n_nodes, device)
         out = unpack_minhash(packed)
-        out._ss_u32 = packed
+        _tag(out, '_ss_u32', packed)
+        # hop-0 marker: lets minhash_prop compute the first hop straight from node ids (ss_first_hop) instead of
+        # gathering this table; voided by any in-place edit (version counter)
+        out._ss_hop0 = (out._version, self._perms(device), self.p)
         return out
 
     def initialise_hll(self, n_nodes):
@@ -503,7 +544,8 @@ class ElphHashes(object):
         device = _compute_device()
         packed = self._init_hll_u8(n_nodes, device)
         out = packed.view(torch.int8)
-        out._ss_u8 = packed
+        _tag(out, '_ss_u8', packed)
+        out._ss_hop0 = (out._version, None, self.p)
         return out
 
     # ---- build ---------------------------------------------------------------------------------------
