@@ -152,6 +152,7 @@ class HopSketch(Mapping):
         self._hll_u8 = hll_u8
         self._make_packed = make_packed  # deferred producer of (mh_u32, hll_u8): hop 0 is only built if somebody reads it
         self._leaves = {}
+        self._leaf_versions = {}
         self.home = home
 
     def _ensure_packed(self):
@@ -178,7 +179,21 @@ class HopSketch(Mapping):
             if val.device != self.home:
                 val = val.to(self.home)
             self._leaves[key] = val
+            self._leaf_versions[key] = val._version
         return val
+
+    def packed(self, device):
+        """(mh_u32, hll_u8) for the kernels.  If a caller edited a materialised leaf in place (the reference's dict
+        holds ordinary tensors, so that is legal) the packed twin is rebuilt from the edited leaf first."""
+        for key in self._KEYS:
+            leaf = self._leaves.get(key)
+            if leaf is not None and leaf._version != self._leaf_versions[key]:
+                if key == 'minhash':
+                    self._mh_u32 = pack_minhash(leaf, device)
+                elif leaf.data_ptr() != self.hll_u8.data_ptr():  # a view of the packed table edits it directly
+                    self._hll_u8 = leaf.to(device).contiguous().view(torch.uint8)
+                self._leaf_versions[key] = leaf._version
+        return self.mh_u32, self.hll_u8
 
     def __iter__(self):
         return iter(self._KEYS)
@@ -603,8 +618,9 @@ class ElphHashes(object):
         for k in range(1, self.max_hops + 1):
             entry = hash_table[k]
             if isinstance(entry, HopSketch) and entry.mh_u32.device == device:
-                mh.append(entry.mh_u32)
-                hll.append(entry.hll_u8)
+                m, l = entry.packed(device)
+                mh.append(m)
+                hll.append(l)
             else:
                 mh.append(_packed_minhash_of(entry['minhash'], device))
                 hll.append(_packed_hll_of(entry['hll'], device))
