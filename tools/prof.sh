@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, via gpurun): bash tools_prof.sh <tag> [bench args]
+# usage (on the GPU box, via gpurun): bash tools/prof.sh <tag> [bench args]
 # 1) rocprofv3 --kernel-trace --stats of bench.py  2) two PMC passes (FETCH_SIZE, WRITE_SIZE) in their own runs.
 # Outputs land in gpurun_out/prof_<tag>/ ; tools/summarise_prof.py turns them into profiles/<tag>_*.{csv,json}
 TAG=$1; shift
