@@ -3,237 +3,116 @@
 // The reference materialises one message x[src] per edge and scatter-maxes it (PyG propagate,
 // hashing.py:34,44).  The MI355X engine instead pulls: edges are grouped by destination once and every
 // hop streams whole neighbour rows.  The order of sources inside a row is unspecified (min / max do not
-// care), which lets the build be a two-level counting sort with NO per-edge global atomics -- on gfx950
-// device-scope atomics from 8 non-coherent XCD L2s are served at the memory side and cost ~45 ns per
-// 1000 edges each way (first version: 0.23 ms for 2.4 M edges, profiles/round1_v1_kernel_stats.csv).
+// care), which lets the build be an MSD radix partition with
+//   * NO per-edge global atomics -- device-scope atomics from 8 non-coherent XCD L2s are served at the memory
+//     side (first version: 0.23 ms for 2.4 M edges), and
+//   * NO scattered small stores -- an 8-byte store per edge into hundreds of open segments reaches the memory side
+//     as 3-5x its useful bytes (second version, PMC: 1.09 GB written for 0.34 GB on a ppa-sized graph).  Every
+//     partition step sorts a 4096-edge tile by key in LDS first and writes it out as contiguous runs.
 //
-//   A1 bucket_count   : each block takes a contiguous slice of the edge list, histograms dst >> shift in
-//                       LDS (a bucket = NB = 1024 consecutive nodes; 256..8192 were measured, 1024 is best on
-//                       every shape), writes its column of the bucket-major [buckets x blocks] count matrix.
-//   A2 bucket_offsets : per bucket, exclusive scan over blocks (column of the matrix) + bucket totals.
-//   A3 bucket_bases   : single block, exclusive scan of bucket totals -> bucket base offsets.
-//   A4 bucket_scatter : same slices as A1; LDS cursors seeded with base[bucket] + offset[bucket][block];
-//                       edges are written as (src, dst) int32 pairs grouped by bucket; also validates src and
-//                       reduces max(id)+1 (= self-loop count of add_self_loops, hashing.py:148).
-//   B  bucket_finish  : one block per bucket: LDS histogram over its NB nodes, LDS scan -> rowptr,
-//                       LDS cursors -> col.
+// A "fine bucket" is 2^node_shift consecutive destination nodes (<= 1024, fewer for dense graphs so that a bucket's
+// edges fit the LDS staging buffer of the last step).
+//   pass 1  count_keys -> scan_block_counts -> scan_bases -> scatter_tiles    edges -> <= 256 buckets by dst >> shift1
+//   pass 2  (only when there are more than 256 fine buckets) the same three steps inside every pass-1 bucket,
+//           a fixed number of workgroups per bucket, <= 256 sub-buckets each
+//   finish  one workgroup per fine bucket: LDS histogram over its nodes, LDS scan -> rowptr, sources placed into an
+//           LDS image of the bucket's col segment and streamed out (oversized buckets: several node sub-ranges)
+// The pass-1 scatter also validates ids and reduces max(id)+1 (the self-loop count of add_self_loops,
+// hashing.py:148); the finish step lists hub rows.  Nothing synchronises with the host.
 #include "ss_common.hpp"
 
 namespace ss {
 
-constexpr int kCsrThreads = 256;
-constexpr int kEdgesPerBlockMin = 4096;   // slice size lower bound (A1 / A4)
-constexpr int kMaxSliceBlocks = 4096;
-constexpr int kMaxBuckets = 4096;         // LDS histogram size of A1 / A4
-constexpr int kMinNodesPerBucket = 1024;
-constexpr int kMaxNodesPerBucket = 16384; // LDS of B: 2 * NB * 4 bytes
-constexpr int kFinishThreads = 1024;
+constexpr int kThreads = 256;
+constexpr int kTile = 4096;            // edges sorted in LDS at a time by the scatter step
+constexpr int kMaxKeys = 256;          // partition fan-out per pass
+constexpr int kMaxBlocks1 = 2048;      // pass-1 slices
+constexpr int kFinishThreads = 512;
+constexpr int kFinishCap = 16384;      // edges staged in LDS by the finish step (64 KiB)
 
 struct CsrPlan {
-    int shift;         // bucket = dst >> shift
-    int nodes_per_bucket;
-    int buckets;
-    int slice_blocks;
-    int64_t slice_edges;
+    int node_shift;       // fine bucket = dst >> node_shift
+    int64_t fine_buckets;
+    bool two_pass;
+    int shift1;           // pass-1 key = dst >> shift1
+    int keys1;            // number of pass-1 buckets (<= 256)
+    int keys2;            // sub-buckets per pass-1 bucket (two_pass only, <= 256)
+    int blocks1;
+    int64_t slice1;
+    int parts2;           // workgroups per pass-1 bucket in pass 2
 };
 
 inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
 {
-    int nb = kMinNodesPerBucket, shift = 10;
-    while ((N + nb - 1) / nb > kMaxBuckets && nb < kMaxNodesPerBucket) { nb <<= 1; ++shift; }
-    if ((N + nb - 1) / nb > kMaxBuckets) return false;
-    p.shift = shift;
-    p.nodes_per_bucket = nb;
-    p.buckets = (int)((N + nb - 1) / nb);
-    if (p.buckets < 1) p.buckets = 1;
-    int64_t blocks = (E + kEdgesPerBlockMin - 1) / kEdgesPerBlockMin;
-    if (blocks < 1) blocks = 1;
-    if (blocks > kMaxSliceBlocks) blocks = kMaxSliceBlocks;
-    p.slice_blocks = (int)blocks;
-    p.slice_edges = (E + blocks - 1) / blocks;
+    if (N < 0 || E < 0 || N >= ((int64_t)1 << 31)) return false;
+    const int64_t n = N > 0 ? N : 1;
+    // fine bucket = 1024 nodes when that gives <= 256 buckets (one partition pass; the finish step copes with dense
+    // buckets through node sub-ranges); otherwise two passes and a bucket sized for about kFinishCap / 2 edges on
+    // average, between 64 and 1024 nodes
+    int shift = 10;
+    if (((n + 1023) >> 10) > kMaxKeys)
+        while (shift > 6 && (E / n) * ((int64_t)1 << shift) > kFinishCap / 2) --shift;
+    p.node_shift = shift;
+    p.fine_buckets = (n + ((int64_t)1 << shift) - 1) >> shift;
+    p.two_pass = p.fine_buckets > kMaxKeys;
+    if (!p.two_pass) {
+        p.shift1 = shift;
+        p.keys1 = (int)p.fine_buckets;
+        p.keys2 = 1;
+    } else {
+        int s1 = shift;
+        while (((n + ((int64_t)1 << s1) - 1) >> s1) > kMaxKeys) ++s1;
+        if (s1 - shift > 8) return false;  // would need a third pass (N > 16 M nodes at 64-node buckets)
+        p.shift1 = s1;
+        p.keys1 = (int)((n + ((int64_t)1 << s1) - 1) >> s1);
+        p.keys2 = 1 << (s1 - shift);
+    }
+    int64_t b1 = (E + kTile - 1) / kTile;
+    if (b1 < 1) b1 = 1;
+    if (b1 > kMaxBlocks1) b1 = kMaxBlocks1;
+    p.blocks1 = (int)b1;
+    p.slice1 = (E + b1 - 1) / b1;
+    int parts = 2048 / (p.keys1 > 0 ? p.keys1 : 1);
+    if (parts < 1) parts = 1;
+    if (parts > 64) parts = 64;
+    p.parts2 = parts;
     return true;
 }
 
-// A1: histogram of dst >> shift over this block's edge slice.  Reads dst only (8 B/edge); edges whose dst is out of
-// range are dropped here and in A4 alike.  counts is bucket-major: counts[bucket * slice_blocks + block].
-__global__ __launch_bounds__(kCsrThreads) void bucket_count_kernel(const int64_t *__restrict__ dst, int64_t E, int64_t N, int shift,
-                                                                   int buckets, int64_t slice_edges, int slice_blocks,
-                                                                   uint32_t *__restrict__ counts, int32_t *__restrict__ err,
-                                                                   unsigned long long *__restrict__ n_self, int32_t *__restrict__ hub_count)
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Workspace {
+    uint32_t *counts1;              // [keys1][blocks1]
+    unsigned long long *base1;      // [keys1 + 1]
+    uint32_t *counts2;              // [keys1][keys2][parts2]
+    unsigned long long *fine_base;  // [fine_buckets + 1]
+    unsigned long long *scratch;    // [1] n_self when the caller does not want it
+    int2 *staged_a, *staged_b;      // [E] each
+    size_t bytes;
+};
+
+inline Workspace carve(const CsrPlan &p, int64_t E, void *base)
 {
-    __shared__ uint32_t hist[kMaxBuckets];
-    // outputs of the LATER kernels of this build (A4: n_self, B: hub_count) are cleared here: saves two memset launches
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *n_self = 0ULL;
-        if (hub_count) *hub_count = 0;
-    }
-    for (int b = threadIdx.x; b < buckets; b += blockDim.x) hist[b] = 0;
-    __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * slice_edges;
-    const int64_t hi = lo + slice_edges < E ? lo + slice_edges : E;
-    bool bad = false;
-    int64_t e = lo + threadIdx.x;
-    for (; e + 3 * (int64_t)kCsrThreads < hi; e += 4 * (int64_t)kCsrThreads) {
-        int64_t d[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = dst[e + k * (int64_t)kCsrThreads];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if ((uint64_t)d[k] < (uint64_t)N) atomicAdd(&hist[d[k] >> shift], 1u);
-            else bad = true;
-        }
-    }
-    for (; e < hi; e += kCsrThreads) {
-        const int64_t d = dst[e];
-        if ((uint64_t)d < (uint64_t)N) atomicAdd(&hist[d >> shift], 1u);
-        else bad = true;
-    }
-    if (bad && err) *err = 1;
-    __syncthreads();
-    for (int b = threadIdx.x; b < buckets; b += blockDim.x) counts[(int64_t)b * slice_blocks + blockIdx.x] = hist[b];
+    Workspace w;
+    char *c = reinterpret_cast<char *>(base);
+    size_t off = 0;
+    auto take = [&](size_t n) { char *r = c ? c + off : nullptr; off += align256(n); return r; };
+    w.counts1 = reinterpret_cast<uint32_t *>(take((size_t)p.keys1 * p.blocks1 * 4));
+    w.base1 = reinterpret_cast<unsigned long long *>(take((size_t)(p.keys1 + 1) * 8));
+    w.counts2 = reinterpret_cast<uint32_t *>(take(p.two_pass ? (size_t)p.keys1 * p.keys2 * p.parts2 * 4 : 0));
+    w.fine_base = reinterpret_cast<unsigned long long *>(take(p.two_pass ? (size_t)(p.fine_buckets + 1) * 8 : 0));
+    w.scratch = reinterpret_cast<unsigned long long *>(take(8));
+    w.staged_a = reinterpret_cast<int2 *>(take((size_t)(E > 0 ? E : 1) * 8));
+    w.staged_b = reinterpret_cast<int2 *>(take(p.two_pass ? (size_t)(E > 0 ? E : 1) * 8 : 0));
+    w.bytes = off;
+    return w;
 }
 
-// one wave per bucket: exclusive scan of the bucket's column over slice blocks (in place), bucket total out
-__global__ __launch_bounds__(kCsrThreads) void bucket_offsets_kernel(uint32_t *__restrict__ counts, int slice_blocks, int buckets,
-                                                                     unsigned long long *__restrict__ bucket_total)
+// ---- block-wide exclusive scan of 256 values, one per thread (kThreads == 256) ---------------------------------------
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t x, uint32_t *wave_tot /* LDS [4] */, uint32_t *total)
 {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int b = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-    if (b >= buckets) return;
-    uint32_t carry = 0;
-    for (int g0 = 0; g0 < slice_blocks; g0 += kWave) {
-        const int g = g0 + lane;
-        const uint32_t x = g < slice_blocks ? counts[(int64_t)b * slice_blocks + g] : 0u;
-        uint32_t inc = x;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
-        }
-        if (g < slice_blocks) counts[(int64_t)b * slice_blocks + g] = carry + inc - x;
-        carry += __shfl(inc, kWave - 1);
-    }
-    if (lane == 0) bucket_total[b] = carry;
-}
-
-// single block: exclusive scan of bucket totals in place (-> bucket bases); grand total to rowptr[N]
-__global__ __launch_bounds__(kCsrThreads) void bucket_bases_kernel(unsigned long long *__restrict__ bucket_total, int buckets,
-                                                                   int64_t *__restrict__ rowptr, int64_t N)
-{
-    __shared__ unsigned long long wave_tot[kCsrThreads / kWave];
-    __shared__ unsigned long long carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    for (int start = 0; start < buckets; start += kCsrThreads) {
-        const int i = start + threadIdx.x;
-        const unsigned long long x = i < buckets ? bucket_total[i] : 0ULL;
-        unsigned long long inc = x;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const unsigned long long o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
-        }
-        if (lane == kWave - 1) wave_tot[wv] = inc;
-        __syncthreads();
-        unsigned long long pre = carry_s;
-        for (int w = 0; w < wv; ++w) pre += wave_tot[w];
-        if (i < buckets) bucket_total[i] = pre + inc - x;
-        __syncthreads();
-        if (threadIdx.x == kCsrThreads - 1) carry_s = pre + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) rowptr[N] = (int64_t)carry_s;
-}
-
-// A4: scatter (src, dst) pairs into their bucket's segment; also reduces max(id) + 1 (the self-loop count of
-// add_self_loops, hashing.py:148).  An out-of-range src sets the error flag and is clamped to 0 (memory safe; the
-// host raises IndexError in strict mode), an out-of-range dst drops the edge exactly as A1 did.
-__global__ __launch_bounds__(kCsrThreads) void bucket_scatter_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                                                                     int64_t E, int64_t N, int shift, int buckets, int64_t slice_edges,
-                                                                     int slice_blocks, const uint32_t *__restrict__ offsets,
-                                                                     const unsigned long long *__restrict__ bucket_base,
-                                                                     int2 *__restrict__ staged /*[E] (src, dst)*/,
-                                                                     unsigned long long *__restrict__ n_self, int32_t *__restrict__ err)
-{
-    __shared__ unsigned long long cursor[kMaxBuckets];
-    __shared__ unsigned long long block_max;
-    for (int b = threadIdx.x; b < buckets; b += blockDim.x)
-        cursor[b] = bucket_base[b] + offsets[(int64_t)b * slice_blocks + blockIdx.x];
-    if (threadIdx.x == 0) block_max = 0;
-    __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * slice_edges;
-    const int64_t hi = lo + slice_edges < E ? lo + slice_edges : E;
-    int64_t my_max = -1;
-    bool bad = false;
-    auto place = [&](int64_t s, int64_t d) {
-        const int64_t mx = s > d ? s : d;
-        my_max = mx > my_max ? mx : my_max;
-        if ((uint64_t)d >= (uint64_t)N) return;
-        if ((uint64_t)s >= (uint64_t)N) { bad = true; s = 0; }
-        const unsigned long long pos = atomicAdd(&cursor[d >> shift], 1ULL);
-        staged[pos] = make_int2((int)s, (int)d);
-    };
-    int64_t e = lo + threadIdx.x;
-    for (; e + 3 * (int64_t)kCsrThreads < hi; e += 4 * (int64_t)kCsrThreads) {
-        int64_t sv[4], dv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sv[k] = src[e + k * (int64_t)kCsrThreads];
-            dv[k] = dst[e + k * (int64_t)kCsrThreads];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) place(sv[k], dv[k]);
-    }
-    for (; e < hi; e += kCsrThreads) place(src[e], dst[e]);
-    unsigned long long m = my_max < 0 ? 0ULL : (unsigned long long)my_max + 1ULL;
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(m, off);
-        m = o > m ? o : m;
-    }
-    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(&block_max, m);
-    if (bad && err) *err = 1;
-    __syncthreads();
-    if (threadIdx.x == 0 && block_max) atomicMax(n_self, block_max);
-}
-
-// one block per bucket
-__global__ __launch_bounds__(kFinishThreads) void bucket_finish_kernel(const int2 *__restrict__ staged,
-                                                                       const unsigned long long *__restrict__ bucket_base,
-                                                                       int buckets, int nodes_per_bucket, int64_t N,
-                                                                       int64_t *__restrict__ rowptr, int32_t *__restrict__ col,
-                                                                       int hub_threshold, int32_t *__restrict__ hub_rows,
-                                                                       int32_t *__restrict__ hub_count)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *cnt = smem;                       // [NB] counts, then cursors
-    uint32_t *excl = smem + nodes_per_bucket;   // [NB] exclusive offsets
-    __shared__ uint32_t wave_tot[kFinishThreads / kWave];
-    const int b = blockIdx.x;
-    const int64_t node0 = (int64_t)b * nodes_per_bucket;
-    const unsigned long long seg_lo = bucket_base[b];
-    const unsigned long long seg_hi = (b + 1 < buckets) ? bucket_base[b + 1] : (unsigned long long)rowptr[N];
-    for (int i = threadIdx.x; i < nodes_per_bucket; i += blockDim.x) cnt[i] = 0;
-    __syncthreads();
-    {
-        unsigned long long e = seg_lo + threadIdx.x;
-        for (; e + 3ULL * blockDim.x < seg_hi; e += 4ULL * blockDim.x) {
-            int y[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) y[k] = staged[e + (unsigned long long)k * blockDim.x].y;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(&cnt[y[k] - (int)node0], 1u);
-        }
-        for (; e < seg_hi; e += blockDim.x) atomicAdd(&cnt[staged[e].y - (int)node0], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of cnt[0..NB): each thread owns a contiguous run
-    const int per = nodes_per_bucket / (int)blockDim.x;  // NB is a power of two >= blockDim.x
-    const int base = threadIdx.x * per;
-    uint32_t run = 0;
-    for (int k = 0; k < per; ++k) run += cnt[base + k];
-    uint32_t inc = run;
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    uint32_t inc = x;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
         const uint32_t o = __shfl_up(inc, off);
@@ -241,46 +120,354 @@ __global__ __launch_bounds__(kFinishThreads) void bucket_finish_kernel(const int
     }
     if (lane == kWave - 1) wave_tot[wv] = inc;
     __syncthreads();
-    uint32_t pre = 0;
-    for (int w = 0; w < wv; ++w) pre += wave_tot[w];
-    uint32_t ex = pre + inc - run;
-    for (int k = 0; k < per; ++k) {
-        const uint32_t c = cnt[base + k];
-        excl[base + k] = ex;
-        if (node0 + base + k < N) rowptr[node0 + base + k] = (int64_t)(seg_lo + ex);
-        if (hub_rows && c > (uint32_t)hub_threshold) hub_rows[atomicAdd(hub_count, 1)] = (int32_t)(node0 + base + k);
-        ex += c;
+    uint32_t pre = 0, tot = 0;
+    for (int w = 0; w < kThreads / kWave; ++w) {
+        if (w < wv) pre += wave_tot[w];
+        tot += wave_tot[w];
     }
+    if (total) *total = tot;
     __syncthreads();
-    for (int i = threadIdx.x; i < nodes_per_bucket; i += blockDim.x) cnt[i] = excl[i];
-    __syncthreads();
-    {
-        unsigned long long e = seg_lo + threadIdx.x;
-        for (; e + 3ULL * blockDim.x < seg_hi; e += 4ULL * blockDim.x) {
-            int2 sd[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sd[k] = staged[e + (unsigned long long)k * blockDim.x];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) col[seg_lo + atomicAdd(&cnt[sd[k].y - (int)node0], 1u)] = sd[k].x;
-        }
-        for (; e < seg_hi; e += blockDim.x) {
-            const int2 sd = staged[e];
-            col[seg_lo + atomicAdd(&cnt[sd.y - (int)node0], 1u)] = sd.x;
-        }
+    return pre + inc - x;
+}
+
+// where a workgroup's edges come from and how they are keyed
+struct PassArgs {
+    const int64_t *src, *dst;            // pass 1 input: slices of the caller's edge list
+    const int2 *staged;                  // pass 2 input: parts of one pass-1 bucket
+    const unsigned long long *seg_base;  // pass 2: base1[keys1 + 1]
+    int64_t E, N, slice;                 // pass 1
+    int shift, sub_shift, keys, parts;   // key = dst >> shift (pass 1) | (dst >> sub_shift) - (bucket << (shift - sub_shift)) (pass 2)
+};
+
+template <bool PASS2>
+__device__ __forceinline__ void block_range(const PassArgs &a, int64_t &lo, int64_t &hi, int &group, int &part, int &parts)
+{
+    if (!PASS2) {
+        group = 0;
+        part = blockIdx.x;
+        parts = gridDim.x;
+        lo = (int64_t)blockIdx.x * a.slice;
+        hi = lo + a.slice < a.E ? lo + a.slice : a.E;
+        if (lo > a.E) lo = a.E;
+    } else {
+        group = blockIdx.x / a.parts;
+        part = blockIdx.x % a.parts;
+        parts = a.parts;
+        const int64_t s = (int64_t)a.seg_base[group], e = (int64_t)a.seg_base[group + 1];
+        const int64_t per = (e - s + a.parts - 1) / a.parts;
+        lo = s + per * part;
+        if (lo > e) lo = e;
+        hi = lo + per < e ? lo + per : e;
     }
 }
 
-inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+template <bool PASS2>
+__device__ __forceinline__ int key_of(const PassArgs &a, int64_t d, int group)
+{
+    return PASS2 ? (int)((d >> a.sub_shift) - ((int64_t)group << (a.shift - a.sub_shift))) : (int)(d >> a.shift);
+}
+
+// counts[(group * keys + key) * parts + part]
+template <bool PASS2>
+__global__ __launch_bounds__(kThreads) void count_keys_kernel(PassArgs a, uint32_t *__restrict__ counts, int32_t *__restrict__ err,
+                                                              unsigned long long *__restrict__ n_self, int32_t *__restrict__ hub_count)
+{
+    __shared__ uint32_t hist[kMaxKeys];
+    if (!PASS2 && blockIdx.x == 0 && threadIdx.x == 0) {  // outputs of later kernels of this build are cleared here
+        *n_self = 0ULL;
+        if (hub_count) *hub_count = 0;
+    }
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t lo, hi;
+    int group, part, parts;
+    block_range<PASS2>(a, lo, hi, group, part, parts);
+    bool bad = false;
+    for (int64_t e0 = lo; e0 < hi; e0 += 4 * kThreads) {
+        int64_t d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t e = e0 + threadIdx.x + (int64_t)k * kThreads;
+            d[k] = e < hi ? (PASS2 ? (int64_t)a.staged[e].y : a.dst[e]) : (int64_t)-1;
+            if (!PASS2 && e < hi && (uint64_t)d[k] >= (uint64_t)a.N) {  // out of range: dropped (and reported)
+                bad = true;
+                d[k] = -1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (d[k] >= 0) atomicAdd(&hist[key_of<PASS2>(a, d[k], group)], 1u);
+    }
+    if (bad && err) *err = 1;
+    __syncthreads();
+    if ((int)threadIdx.x < a.keys) counts[((int64_t)group * a.keys + threadIdx.x) * parts + part] = hist[threadIdx.x];
+}
+
+// pass 1: one wave per key: exclusive scan of that key's counts over the slices (in place) + key total
+__global__ __launch_bounds__(kThreads) void scan_block_counts_kernel(uint32_t *__restrict__ counts, int blocks, int keys,
+                                                                     unsigned long long *__restrict__ key_total)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int k = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
+    if (k >= keys) return;
+    unsigned long long carry = 0;
+    for (int g0 = 0; g0 < blocks; g0 += kWave) {
+        const int g = g0 + lane;
+        const uint32_t x = g < blocks ? counts[(int64_t)k * blocks + g] : 0u;
+        uint32_t inc = x;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        // offsets inside one key stay below 2^32 (E < 2^32 per key is enforced by the int32 staging anyway)
+        if (g < blocks) counts[(int64_t)k * blocks + g] = (uint32_t)carry + inc - x;
+        carry += __shfl(inc, kWave - 1);
+    }
+    if (lane == 0) key_total[k] = carry;
+}
+
+// pass 1: single workgroup: key totals -> exclusive bases (in place), grand total appended and written to rowptr[N]
+__global__ __launch_bounds__(kThreads) void scan_bases_kernel(unsigned long long *__restrict__ key_total, int keys,
+                                                              int64_t *__restrict__ rowptr, int64_t N)
+{
+    __shared__ unsigned long long vals[kMaxKeys];
+    vals[threadIdx.x] = (int)threadIdx.x < keys ? key_total[threadIdx.x] : 0ULL;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // <= 256 values: a serial scan is a few hundred cycles
+        unsigned long long run = 0;
+        for (int k = 0; k < keys; ++k) {
+            const unsigned long long v = vals[k];
+            vals[k] = run;
+            run += v;
+        }
+        key_total[keys] = run;
+        rowptr[N] = (int64_t)run;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < keys) key_total[threadIdx.x] = vals[threadIdx.x];
+}
+
+// pass 2: one workgroup per pass-1 bucket: scan its [keys2][parts2] matrix (key-major) into offsets relative to the
+// bucket's segment start, and write the absolute bases of its fine buckets
+__global__ __launch_bounds__(kThreads) void scan_sub_counts_kernel(uint32_t *__restrict__ counts2, int keys2, int parts2,
+                                                                   const unsigned long long *__restrict__ base1,
+                                                                   unsigned long long *__restrict__ fine_base, int64_t fine_buckets,
+                                                                   int keys1)
+{
+    __shared__ uint32_t wave_tot[kThreads / kWave];
+    const int c = blockIdx.x;
+    uint32_t *m = counts2 + (int64_t)c * keys2 * parts2;
+    uint32_t sum = 0;  // thread k owns key k: its parts2 counters are consecutive
+    if ((int)threadIdx.x < keys2)
+        for (int q = 0; q < parts2; ++q) sum += m[(int64_t)threadIdx.x * parts2 + q];
+    const uint32_t ex = block_exclusive_scan_256(sum, wave_tot, nullptr);
+    if ((int)threadIdx.x < keys2) {
+        uint32_t run = ex;
+        for (int q = 0; q < parts2; ++q) {
+            const uint32_t v = m[(int64_t)threadIdx.x * parts2 + q];
+            m[(int64_t)threadIdx.x * parts2 + q] = run;
+            run += v;
+        }
+        const int64_t f = (int64_t)c * keys2 + threadIdx.x;
+        if (f < fine_buckets) fine_base[f] = base1[c] + ex;
+    }
+    if (c == keys1 - 1 && threadIdx.x == 0) fine_base[fine_buckets] = base1[keys1];
+}
+
+// tile-sorted scatter: every 4096-edge tile is ordered by key in LDS, then written as contiguous runs
+template <bool PASS2>
+__global__ __launch_bounds__(kThreads) void scatter_tiles_kernel(PassArgs a, const uint32_t *__restrict__ offsets,
+                                                                 const unsigned long long *__restrict__ key_base, int2 *__restrict__ out,
+                                                                 unsigned long long *__restrict__ n_self, int32_t *__restrict__ err)
+{
+    __shared__ int2 sorted[kTile];
+    __shared__ uint32_t tile_hist[kMaxKeys], tile_off[kMaxKeys], wave_tot[kThreads / kWave];
+    __shared__ unsigned long long cursor[kMaxKeys];
+    __shared__ unsigned long long block_max;
+    int64_t lo, hi;
+    int group, part, parts;
+    block_range<PASS2>(a, lo, hi, group, part, parts);
+    cursor[threadIdx.x] = 0;
+    if ((int)threadIdx.x < a.keys) {
+        const uint32_t off = offsets[((int64_t)group * a.keys + threadIdx.x) * parts + part];
+        cursor[threadIdx.x] = PASS2 ? a.seg_base[group] + off : key_base[threadIdx.x] + off;
+    }
+    tile_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) block_max = 0;
+    __syncthreads();
+    constexpr int PER = kTile / kThreads;  // 16 edges per thread and tile
+    int64_t my_max = -1;
+    bool bad = false;
+    for (int64_t t0 = lo; t0 < hi; t0 += kTile) {
+        int2 ed[PER];
+        int key[PER];
+        uint32_t rank[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int64_t e = t0 + threadIdx.x + (int64_t)k * kThreads;
+            key[k] = -1;
+            ed[k] = make_int2(0, 0);
+            if (e < hi) {
+                int64_t s, d;
+                if (PASS2) {
+                    const int2 v = a.staged[e];
+                    s = v.x;
+                    d = v.y;
+                } else {
+                    s = a.src[e];
+                    d = a.dst[e];
+                    const int64_t mx = s > d ? s : d;
+                    my_max = mx > my_max ? mx : my_max;
+                    if ((uint64_t)d >= (uint64_t)a.N) continue;               // dropped, exactly as count_keys did
+                    if ((uint64_t)s >= (uint64_t)a.N) { bad = true; s = 0; }  // memory safe; the host raises in strict mode
+                }
+                ed[k] = make_int2((int)s, (int)d);
+                key[k] = key_of<PASS2>(a, d, group);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) rank[k] = key[k] >= 0 ? atomicAdd(&tile_hist[key[k]], 1u) : 0u;
+        __syncthreads();
+        uint32_t tile_n = 0;
+        const uint32_t ex = block_exclusive_scan_256(tile_hist[threadIdx.x], wave_tot, &tile_n);
+        tile_off[threadIdx.x] = ex;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (key[k] >= 0) sorted[tile_off[key[k]] + rank[k]] = ed[k];
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < tile_n; q += kThreads) {
+            const int2 v = sorted[q];
+            const int kq = key_of<PASS2>(a, (int64_t)v.y, group);
+            out[cursor[kq] + (q - tile_off[kq])] = v;
+        }
+        __syncthreads();
+        cursor[threadIdx.x] += tile_hist[threadIdx.x];
+        tile_hist[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    if (!PASS2) {
+        unsigned long long m = my_max < 0 ? 0ULL : (unsigned long long)my_max + 1ULL;
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(m, off);
+            m = o > m ? o : m;
+        }
+        if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(&block_max, m);
+        if (bad && err) *err = 1;
+        __syncthreads();
+        if (threadIdx.x == 0 && block_max) atomicMax(n_self, block_max);
+    }
+}
+
+// finish: one workgroup per fine bucket
+__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__restrict__ staged, const unsigned long long *__restrict__ fine_base,
+                                                                int node_shift, int64_t N, int64_t *__restrict__ rowptr,
+                                                                int32_t *__restrict__ col, int hub_threshold, int32_t *__restrict__ hub_rows,
+                                                                int32_t *__restrict__ hub_count)
+{
+    __shared__ uint32_t cnt[1024], excl[1024 + 1];
+    __shared__ int32_t image[kFinishCap];  // LDS image of (a node sub-range of) the bucket's col segment
+    __shared__ uint32_t wave_tot[kFinishThreads / kWave];
+    const int nb = 1 << node_shift;  // <= 1024 nodes
+    const int64_t node0 = (int64_t)blockIdx.x << node_shift;
+    const unsigned long long seg_lo = fine_base[blockIdx.x], seg_hi = fine_base[blockIdx.x + 1];
+    const uint32_t seg_n = (uint32_t)(seg_hi - seg_lo);
+    for (int i = threadIdx.x; i < nb; i += kFinishThreads) cnt[i] = 0;
+    __syncthreads();
+    for (uint32_t q0 = 0; q0 < seg_n; q0 += 4 * kFinishThreads) {
+        int y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t q = q0 + threadIdx.x + k * kFinishThreads;
+            y[k] = q < seg_n ? staged[seg_lo + q].y - (int)node0 : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (y[k] >= 0) atomicAdd(&cnt[y[k]], 1u);
+    }
+    __syncthreads();
+    {   // exclusive scan of cnt[0..nb): two counters per thread at nb = 1024
+        const int per = (nb + kFinishThreads - 1) / kFinishThreads;
+        const int b0 = threadIdx.x * per;
+        uint32_t run = 0;
+        for (int k = 0; k < per; ++k) run += (b0 + k < nb) ? cnt[b0 + k] : 0u;
+        uint32_t inc = run;
+        const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == kWave - 1) wave_tot[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (int w = 0; w < wv; ++w) pre += wave_tot[w];
+        uint32_t ex = pre + inc - run;
+        for (int k = 0; k < per; ++k) {
+            if (b0 + k >= nb) break;
+            const uint32_t c = cnt[b0 + k];
+            excl[b0 + k] = ex;
+            if (node0 + b0 + k < N) {
+                rowptr[node0 + b0 + k] = (int64_t)(seg_lo + ex);
+                if (hub_rows && c > (uint32_t)hub_threshold) hub_rows[atomicAdd(hub_count, 1)] = (int32_t)(node0 + b0 + k);
+            }
+            ex += c;
+        }
+        if (threadIdx.x == 0) excl[nb] = seg_n;
+    }
+    __syncthreads();
+    // place the sources: node sub-ranges [n_lo, n_hi) whose edges fit the LDS image (one range when seg_n <= cap).
+    // Every sub-range re-reads the whole segment, so a bucket far above the cap (hub-heavy buckets of power-law graphs)
+    // is placed in ONE sweep straight into global memory instead: scattered 4-byte stores, but only for those buckets.
+    const bool all_direct = seg_n > 4u * (uint32_t)kFinishCap;
+    int n_lo = 0;
+    while (n_lo < nb) {
+        // largest n_hi with excl[n_hi] - excl[n_lo] <= cap; at least one node (a single node above the cap is streamed
+        // straight to global memory -- its positions are consecutive anyway).  Every thread runs the same search.
+        int lo_b = n_lo + 1, hi_b = nb;
+        while (lo_b < hi_b) {
+            const int mid = (lo_b + hi_b + 1) >> 1;
+            if (excl[mid] - excl[n_lo] <= (uint32_t)kFinishCap) lo_b = mid; else hi_b = mid - 1;
+        }
+        const int n_hi = all_direct ? nb : lo_b;
+        const uint32_t r_lo = excl[n_lo], r_n = excl[n_hi] - r_lo;
+        const bool direct = r_n > (uint32_t)kFinishCap;  // single oversized node, or the whole oversized bucket
+        for (int i = n_lo + threadIdx.x; i < n_hi; i += kFinishThreads) cnt[i] = excl[i] - r_lo;  // cursors relative to the range
+        __syncthreads();
+        if (r_n > 0) {
+            for (uint32_t q0 = 0; q0 < seg_n; q0 += 4 * kFinishThreads) {
+                int2 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t q = q0 + threadIdx.x + k * kFinishThreads;
+                    v[k] = q < seg_n ? staged[seg_lo + q] : make_int2(0, -1);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int y = v[k].y - (int)node0;
+                    if (v[k].y < 0 || y < n_lo || y >= n_hi) continue;
+                    const uint32_t pos = atomicAdd(&cnt[y], 1u);
+                    if (direct) col[seg_lo + r_lo + pos] = v[k].x;
+                    else image[pos] = v[k].x;
+                }
+            }
+            __syncthreads();
+            if (!direct)
+                for (uint32_t q = threadIdx.x; q < r_n; q += kFinishThreads) col[seg_lo + r_lo + q] = image[q];
+        }
+        __syncthreads();
+        n_lo = n_hi;
+    }
+}
 
 }  // namespace ss
 
-// workspace layout: [count matrix: slice_blocks*buckets u32][bucket totals/bases: buckets+1 u64][staged edges: E int2]
 extern "C" size_t ss_csr_workspace_bytes(int64_t N, int64_t E)
 {
     ss::CsrPlan p;
-    if (N < 0 || E < 0 || !ss::make_plan(N, E, p)) return 0;
-    return ss::align256((size_t)p.slice_blocks * p.buckets * 4) + ss::align256((size_t)(p.buckets + 1) * 8) +
-           ss::align256((size_t)(E > 0 ? E : 1) * 8);
+    if (!ss::make_plan(N, E, p)) return 0;
+    return ss::carve(p, E, nullptr).bytes;
 }
 
 extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
@@ -290,40 +477,55 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     using namespace ss;
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || !rowptr) return SS_ERR_INVALID_ARG;
     if (E > 0 && (!src || !dst || !col)) return SS_ERR_INVALID_ARG;
+    if ((hub_rows == nullptr) != (hub_count == nullptr)) return SS_ERR_INVALID_ARG;
     CsrPlan p;
-    if (!make_plan(N, E, p)) return SS_ERR_UNSUPPORTED;  // N > 64 M nodes
+    if (!make_plan(N, E, p)) return SS_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < ss_csr_workspace_bytes(N, E)) return SS_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
-    char *ws = reinterpret_cast<char *>(workspace);
-    auto *counts = reinterpret_cast<uint32_t *>(ws);
-    ws += align256((size_t)p.slice_blocks * p.buckets * 4);
-    auto *bucket_total = reinterpret_cast<unsigned long long *>(ws);
-    ws += align256((size_t)(p.buckets + 1) * 8);
-    auto *staged = reinterpret_cast<int2 *>(ws);
-
-    if ((hub_rows == nullptr) != (hub_count == nullptr)) return SS_ERR_INVALID_ARG;
     if (N == 0 || E == 0) {
         if (n_self_loops_out && hipMemsetAsync(n_self_loops_out, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
         if (hub_count && hipMemsetAsync(hub_count, 0, 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
         if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
         return SS_OK;
     }
-    unsigned long long *n_self = reinterpret_cast<unsigned long long *>(n_self_loops_out);
-    if (!n_self) n_self = bucket_total + p.buckets;  // spare workspace slot when the caller does not want the value
-    hipLaunchKernelGGL(bucket_count_kernel, dim3(p.slice_blocks), dim3(kCsrThreads), 0, stream, dst, E, N, p.shift, p.buckets,
-                       p.slice_edges, p.slice_blocks, counts, err_flag, n_self, hub_count);
+    const Workspace w = carve(p, E, workspace);
+    unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
+
+    // ---- pass 1 ----
+    PassArgs a1 = {};
+    a1.src = src; a1.dst = dst; a1.E = E; a1.N = N; a1.slice = p.slice1; a1.shift = p.shift1; a1.keys = p.keys1;
+    hipLaunchKernelGGL(count_keys_kernel<false>, dim3(p.blocks1), dim3(kThreads), 0, stream, a1, w.counts1, err_flag, n_self, hub_count);
     SS_LAUNCH_CHECK();
-    const int waves_per_block = kCsrThreads / kWave;
-    hipLaunchKernelGGL(bucket_offsets_kernel, dim3((p.buckets + waves_per_block - 1) / waves_per_block), dim3(kCsrThreads), 0, stream,
-                       counts, p.slice_blocks, p.buckets, bucket_total);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3((p.keys1 + 3) / 4), dim3(kThreads), 0, stream, w.counts1, p.blocks1, p.keys1, w.base1);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bucket_bases_kernel, dim3(1), dim3(kCsrThreads), 0, stream, bucket_total, p.buckets, rowptr, N);
+    hipLaunchKernelGGL(scan_bases_kernel, dim3(1), dim3(kThreads), 0, stream, w.base1, p.keys1, rowptr, N);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(p.slice_blocks), dim3(kCsrThreads), 0, stream, src, dst, E, N, p.shift, p.buckets,
-                       p.slice_edges, p.slice_blocks, counts, bucket_total, staged, n_self, err_flag);
+    hipLaunchKernelGGL(scatter_tiles_kernel<false>, dim3(p.blocks1), dim3(kThreads), 0, stream, a1, w.counts1, w.base1, w.staged_a, n_self,
+                       err_flag);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bucket_finish_kernel, dim3(p.buckets), dim3(p.nodes_per_bucket < kFinishThreads ? p.nodes_per_bucket : kFinishThreads), (size_t)p.nodes_per_bucket * 8, stream, staged,
-                       bucket_total, p.buckets, p.nodes_per_bucket, N, rowptr, col, (int)hub_threshold, hub_rows, hub_count);
+    const int2 *final_staged = w.staged_a;
+    const unsigned long long *fine_base = w.base1;
+    // ---- pass 2 ----
+    if (p.two_pass) {
+        PassArgs a2 = {};
+        a2.staged = w.staged_a; a2.seg_base = w.base1; a2.N = N; a2.shift = p.shift1; a2.sub_shift = p.node_shift; a2.keys = p.keys2;
+        a2.parts = p.parts2;
+        const unsigned blocks2 = (unsigned)(p.keys1 * p.parts2);
+        hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks2), dim3(kThreads), 0, stream, a2, w.counts2, (int32_t *)nullptr,
+                           (unsigned long long *)nullptr, (int32_t *)nullptr);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scan_sub_counts_kernel, dim3(p.keys1), dim3(kThreads), 0, stream, w.counts2, p.keys2, p.parts2, w.base1,
+                           w.fine_base, p.fine_buckets, p.keys1);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks2), dim3(kThreads), 0, stream, a2, w.counts2, w.base1, w.staged_b,
+                           (unsigned long long *)nullptr, (int32_t *)nullptr);
+        SS_LAUNCH_CHECK();
+        final_staged = w.staged_b;
+        fine_base = w.fine_base;
+    }
+    // ---- finish ----
+    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p.fine_buckets), dim3(kFinishThreads), 0, stream, final_staged, fine_base, p.node_shift,
+                       N, rowptr, col, (int)hub_threshold, hub_rows, hub_count);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
