@@ -641,7 +641,16 @@ class ElphHashes(object):
         if cards is None:
             cd = torch.zeros((N, h), dtype=torch.float32, device=device)
         else:
-            cd = cards.to(device=device, dtype=torch.float32)
+            # ELPH keeps `cards` on the CPU and the reference re-uploads it on every call (hashing.py:274): keep a device
+            # twin on the tensor, invalidated by in-place edits, so repeated eval batches do not pay the copy again
+            tag = getattr(cards, '_ss_cards', None)
+            if cards.device == device and cards.dtype == torch.float32:
+                cd = cards
+            elif tag is not None and tag[0] == cards._version and tag[1].device == device:
+                cd = tag[1]
+            else:
+                cd = cards.to(device=device, dtype=torch.float32)
+                _tag(cards, '_ss_cards', cd)
             if cd.dim() != 2 or cd.size(0) != N or cd.size(1) < h:
                 raise ValueError(f'cards must have shape [{N}, >= {h}], got {tuple(cd.shape)}')
             if cd.stride(1) != 1:
