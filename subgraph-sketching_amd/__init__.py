@@ -4,8 +4,8 @@ Import name: `subgraph_sketching_amd` (see /subgraph_sketching_amd.py; the direc
 hyphenated name).  Public surface = the reference's src/hashing.py surface.
 """
 from .hashing import (LABEL_LOOKUP, ElphHashes, HllPropagation, HopSketch, MinhashPropagation, SketchTable,
-                      build_csr, pack_minhash, unpack_minhash)
+                      build_csr, load_sketches, pack_minhash, save_sketches, unpack_minhash)
 from . import _native, hll_tables, dist
 
 __all__ = ['LABEL_LOOKUP', 'ElphHashes', 'HllPropagation', 'MinhashPropagation', 'SketchTable', 'HopSketch',
-           'build_csr', 'pack_minhash', 'unpack_minhash', 'hll_tables', 'dist']
+           'build_csr', 'pack_minhash', 'unpack_minhash', 'save_sketches', 'load_sketches', 'hll_tables', 'dist']

@@ -13,6 +13,7 @@ leaves are only materialised if somebody reads them (torch.save does); the kerne
 """
 import logging
 import weakref
+from collections import OrderedDict
 from collections.abc import Mapping
 from ctypes import byref, c_float, c_void_p
 
@@ -201,15 +202,46 @@ class HopSketch(Mapping):
     def __len__(self):
         return len(self._KEYS)
 
-    def __reduce__(self):  # pickles (torch.save) as the reference's plain dict of tensors
-        return (dict, (dict(self.items()),))
-
-
-class SketchTable(dict):
-    """{hop: HopSketch}; pickles as a plain dict of dicts (reference datasets/elph.py:204 torch.saves it)"""
-
     def __reduce__(self):
-        return (dict, ({k: dict(v.items()) if isinstance(v, HopSketch) else v for k, v in self.items()},))
+        # pickles (torch.save, datasets/elph.py:204) as a plain mapping of the two reference-shaped tensors; OrderedDict
+        # because it is what torch.load's default weights_only unpickler accepts as a callable (torch >= 2.6)
+        return (OrderedDict, ([(k, self[k]) for k in self._KEYS],))
+
+
+# {hop: HopSketch}: a plain dict, so that torch.save / torch.load (weights_only) treat it exactly like the reference's
+SketchTable = dict
+
+
+PACKED_FORMAT = 'subgraph-sketch-packed-v1'
+
+
+def save_sketches(path, table, cards):
+    """packed on-disk cache: uint32 MinHash + uint8 HLL per hop (768 B per node and hop at the defaults instead of the
+    1 280 B of the reference's int64/int8 `torch.save(hashes)` cache, datasets/elph.py:204).  Plain tensors and
+    scalars only, so `torch.load(..., weights_only=True)` reads it."""
+    hops = {}
+    for k, entry in table.items():
+        if isinstance(entry, HopSketch):
+            mh, hll = entry.packed(entry.mh_u32.device)
+        else:
+            device = _compute_device(entry['minhash'], entry['hll'])
+            mh, hll = _packed_minhash_of(entry['minhash'], device), _packed_hll_of(entry['hll'], device)
+        hops[int(k)] = {'minhash_u32': mh.cpu(), 'hll_u8': hll.cpu()}
+    torch.save({'format': PACKED_FORMAT, 'hops': hops, 'cards': cards.cpu()}, path)
+
+
+def load_sketches(path, device=None):
+    """read a packed cache (save_sketches) or the reference's own cache files back into (SketchTable, cards).
+    The reference's format ({k: {'hll': int8, 'minhash': int64}}) is returned as loaded -- get_subgraph_features
+    accepts it directly; pass the cards file separately in that case."""
+    blob = torch.load(path, map_location='cpu', weights_only=True)
+    if not (isinstance(blob, dict) and blob.get('format') == PACKED_FORMAT):
+        return blob, None
+    device = device or _compute_device()
+    table = SketchTable()
+    for k, entry in blob['hops'].items():
+        table[int(k)] = HopSketch(entry['minhash_u32'].to(device), entry['hll_u8'].to(device), device)
+    return table, blob['cards'].to(device)
 
 
 def pack_minhash(x, device=None):

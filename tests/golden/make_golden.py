@@ -215,6 +215,10 @@ def main():
     g['feat_h2_1d'] = ref.ElphHashes(a).get_subgraph_features(links[0], {k: tables[k] for k in range(3)},
                                                               cards[:, :2]).numpy()
     np.savez_compressed(os.path.join(HERE, 'g3_g4_ba40.npz'), **g)
+    # the reference's own on-disk cache format (datasets/elph.py:200-204: torch.save of the hashes dict and of cards),
+    # written by the reference's objects themselves: the --load_hashes compatibility fixture
+    torch.save({k: tables[k] for k in range(3)}, os.path.join(HERE, 'ref_ba40_hashcache.pt'))
+    torch.save(cards[:, :2].clone(), os.path.join(HERE, 'ref_ba40_cardcache.pt'))
 
     # ---- G3b: other (p, P) parameterisations on the same graph ------------------------------
     g = {'edge_index': ei, 'num_nodes': np.asarray(n), 'links': links.numpy()}
