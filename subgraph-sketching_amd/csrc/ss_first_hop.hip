@@ -20,6 +20,11 @@
 
 namespace ss {
 
+#ifndef SS_FORCE_EXACT_FIRST_HOP
+#define SS_FORCE_EXACT_FIRST_HOP 0
+#endif
+constexpr bool kForceExactFirstHop = SS_FORCE_EXACT_FIRST_HOP;  // build-time switch: every row through the exact walk
+
 template <int PPL /* permutations per lane = P / 64 */, bool DO_MH, bool DO_HLL>
 __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
                                                         uint32_t *__restrict__ mh_out, int p, uint8_t *__restrict__ hll_out,
@@ -54,7 +59,17 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
 
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
     const int total = deg + (i < n_self ? 1 : 0);
-    first_hop_walk<PPL, DO_MH, DO_HLL>(g.col + rb, deg, total, i, 0, 1, p, a, b, acc, my_row, lane);
+    if (DO_MH && !DO_HLL && !kForceExactFirstHop) {
+        // MinHash alone: two-phase walk (one multiply per neighbour and permutation); the rare ambiguous row is redone exactly
+        const bool amb = total > 0 && first_hop_minhash_fast<PPL>(g.col + rb, deg, total, i, a, b, acc, lane);
+        if (__any(amb)) {
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
+            first_hop_walk<PPL, true, false>(g.col + rb, deg, total, i, 0, 1, p, a, b, acc, my_row, lane);
+        }
+    } else {
+        first_hop_walk<PPL, DO_MH, DO_HLL>(g.col + rb, deg, total, i, 0, 1, p, a, b, acc, my_row, lane);
+    }
 
     if (DO_MH) {
         if (total == 0) {

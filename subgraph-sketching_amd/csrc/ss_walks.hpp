@@ -128,6 +128,83 @@ __device__ __forceinline__ uint32_t pack_hll_quad(const uint32_t *row, int lane)
     return r4.x | (r4.y << 8) | (r4.z << 16) | (r4.w << 24);
 }
 
+// ---- two-phase MinHash first hop ----------------------------------------------------------------------------------------
+// With x = (a*h + b) mod 2^64, the permuted hash is r = x mod (2^61 - 1) = (x & M) + (x >> 61) [- M], so unless the
+// low word of x is within 8 of 2^32 its low 32 bits are simply   r32 = lo32(x) + (x >> 61),   0 <= x >> 61 <= 7.
+// The first-hop kernel is bound by its VALU instruction count (measured: ~5 cycles per wave64 instruction whatever the
+// opcode), and the exact hash costs 10 instructions per (neighbour, permutation).  Phase 1 therefore only finds, per
+// permutation, WHICH neighbour attains the minimum, with 4 instructions per pair: x' = lo32(a_lo*h_lo + b_lo + 8)
+// (v_mad_u64_u32; the +8 makes any low word that could wrap show up as x' < 8), key = x' with its low 6 bits replaced
+// by the neighbour's slot in the 64-neighbour batch (v_bfi_b32), and the two smallest keys (v_med3_u32, v_min_u32).
+// After each batch the hash of the slot holding the smallest key is fetched across lanes; phase 2 evaluates the
+// exact hash once, for that neighbour.  The result is exact unless the two smallest keys fall into the same or
+// adjacent 64-wide buckets (the order inside a bucket is by slot, not by value, and r32 may add up to 7) or a wrap is
+// possible (bucket 0): probability ~4e-6 per (row, permutation); such rows are reported and redone by the exact walk.
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <int PPL>
+__device__ __forceinline__ bool first_hop_minhash_fast(const int32_t *__restrict__ nb, int deg, int total, int64_t self_row,
+                                                       const uint64_t (&a)[PPL], const uint64_t (&b)[PPL], uint32_t (&acc)[PPL], int lane)
+{
+    uint32_t m1[PPL], m2[PPL], h1_lo[PPL], h1_hi[PPL], a_lo[PPL], b8[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        m1[q] = m2[q] = 0xFFFFFFFFu;
+        h1_lo[q] = h1_hi[q] = 0u;
+        a_lo[q] = (uint32_t)a[q];
+        b8[q] = (uint32_t)b[q] + 8u;
+    }
+    for (int base = 0; base < total; base += kWave) {
+        const int t = base + lane;
+        const int64_t nid = t < deg ? (int64_t)nb[t] : self_row;
+        const uint64_t hv = hash_u64((uint64_t)(nid + 1));
+        const uint32_t hv_lo = (uint32_t)hv, hv_hi = (uint32_t)(hv >> 32);
+        const int cnt = total - base < kWave ? total - base : kWave;
+        uint32_t before[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) before[q] = m1[q];
+        auto update = [&](uint32_t h_lo, uint32_t slot) {
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const uint32_t x = a_lo[q] * h_lo + b8[q];
+                const uint32_t key = (x & ~63u) | (slot & 63u);  // v_bfi_b32
+                m2[q] = umed3(m1[q], m2[q], key);       // second smallest key so far
+                m1[q] = key < m1[q] ? key : m1[q];
+            }
+        };
+        int k = 0;
+        for (; k + 3 < cnt; k += 4) {
+            uint32_t hl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) hl[u] = (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k + u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) update(hl[u], (uint32_t)(k + u));
+        }
+        for (; k < cnt; ++k) update((uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k), (uint32_t)k);
+        // the batch's hashes still sit one per lane: fetch the one whose slot now holds the smallest key
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const int slot = (int)(m1[q] & 63u);
+            const uint32_t cand_lo = (uint32_t)__shfl((int)hv_lo, slot), cand_hi = (uint32_t)__shfl((int)hv_hi, slot);
+            const bool changed = m1[q] != before[q];
+            h1_lo[q] = changed ? cand_lo : h1_lo[q];
+            h1_hi[q] = changed ? cand_hi : h1_hi[q];
+        }
+    }
+    bool ambiguous = false;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        acc[q] = permuted_hash(a[q], b[q], ((uint64_t)h1_hi[q] << 32) | h1_lo[q]);
+        ambiguous |= (m1[q] < 64u) | ((m2[q] >> 6) - (m1[q] >> 6) <= 1u);
+    }
+    return ambiguous;
+}
+
 // HLL table hop for FOUR destination rows per wavefront: one 16-lane DPP row per destination, lane c owns the 16-byte
 // chunk c of the 256-byte HLL row.  Compared with one destination per wave (hll_walk + two cross-group shuffles +
 // an epilogue that uses 16 of 64 lanes) this keeps 4x the loads in flight per wave and runs the cardinality
