@@ -153,117 +153,6 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
     }
 }
 
-// MinHash first hop, FOUR consecutive destinations per wavefront.  The rows of consecutive destinations are adjacent in
-// the CSR, so one coalesced load fetches the neighbour ids of all four (lanes 0..59; lanes 60..63 take the four
-// implicit self loops), every lane hashes its id once, and the wave then runs the two-phase walk (ss_walks.hpp) over
-// each row's slot range.  Against one row per wave this amortises the dependent load chain and the 25-instruction
-// hash over four rows (98 -> ~75 us on the bench graph).  Groups whose rows do not fit 60 slots fall back to the
-// single-row walk, hub rows are left to the hub kernel, ambiguous rows are redone exactly.
-template <int PPL>
-__global__ __launch_bounds__(256) void first_hop_mh4_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
-                                                            uint32_t *__restrict__ mh_out, int p, bool skip_hubs)
-{
-    constexpr int P = PPL * kWave, R = 4, kSelfLane = 60;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x / kWave) + wave) * R;
-    if (i0 >= g.N) return;
-    const int rows = (int)(g.N - i0 < R ? g.N - i0 : R);
-    const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
-    uint64_t a[PPL], b[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-        a[q] = pa[lane + kWave * q];
-        b[q] = pb[lane + kWave * q];
-    }
-    int64_t rp[R + 1];
-#pragma unroll
-    for (int r = 0; r <= R; ++r) rp[r] = g.rowptr[i0 + (r < rows ? r : rows)];
-    const int span = (int)(rp[rows] - rp[0]);
-    bool any_hub = false;
-#pragma unroll
-    for (int r = 0; r < R; ++r) any_hub |= r < rows && skip_hubs && (int)(rp[r + 1] - rp[r]) > g.hub_threshold;
-
-    if (span <= kSelfLane && !any_hub) {
-        // one batch for the whole group
-        const int64_t nid = lane < span ? (int64_t)g.col[rp[0] + lane] : i0 + (lane >= kSelfLane ? lane - kSelfLane : 0);
-        const uint64_t hv = hash_u64((uint64_t)(nid + 1));
-        const uint32_t hv_lo = (uint32_t)hv, hv_hi = (uint32_t)(hv >> 32);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (r >= rows) break;
-            const int64_t i = i0 + r;
-            const int off = (int)(rp[r] - rp[0]), deg = (int)(rp[r + 1] - rp[r]);
-            const bool self = i < n_self;
-            uint32_t acc[PPL];
-            if (deg + (self ? 1 : 0) == 0) {
-#pragma unroll
-                for (int q = 0; q < PPL; ++q) acc[q] = 0u;  // no in-edge, no self loop: all-zero row
-            } else {
-                uint32_t m1[PPL], m2[PPL], a_lo[PPL], b8[PPL];
-#pragma unroll
-                for (int q = 0; q < PPL; ++q) {
-                    m1[q] = m2[q] = 0xFFFFFFFFu;
-                    a_lo[q] = (uint32_t)a[q];
-                    b8[q] = (uint32_t)b[q] + 8u;
-                }
-                auto update = [&](int slot) {
-                    const uint32_t h_lo = (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, slot);
-#pragma unroll
-                    for (int q = 0; q < PPL; ++q) {
-                        const uint32_t x = a_lo[q] * h_lo + b8[q];
-                        const uint32_t key = (x & ~63u) | ((uint32_t)slot & 63u);
-                        m2[q] = umed3(m1[q], m2[q], key);
-                        m1[q] = key < m1[q] ? key : m1[q];
-                    }
-                };
-                int k = off;
-                for (; k + 3 < off + deg; k += 4) { update(k); update(k + 1); update(k + 2); update(k + 3); }
-                for (; k < off + deg; ++k) update(k);
-                if (self) update(kSelfLane + r);
-                bool amb = false;
-#pragma unroll
-                for (int q = 0; q < PPL; ++q) {
-                    const int slot = (int)(m1[q] & 63u);
-                    const uint64_t h = ((uint64_t)(uint32_t)__shfl((int)hv_hi, slot) << 32) | (uint32_t)__shfl((int)hv_lo, slot);
-                    acc[q] = permuted_hash(a[q], b[q], h);
-                    amb |= (m1[q] < 64u) | ((m2[q] >> 6) - (m1[q] >> 6) <= 1u);
-                }
-                if (__any(amb)) {
-#pragma unroll
-                    for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
-                    first_hop_walk<PPL, true, false>(g.col + rp[r], deg, deg + (self ? 1 : 0), i, 0, 1, p, a, b, acc, nullptr, lane);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = acc[q];
-        }
-        return;
-    }
-    // fallback: one row at a time
-    for (int r = 0; r < rows; ++r) {
-        const int64_t i = i0 + r;
-        const int deg = (int)(rp[r + 1] - rp[r]);
-        if (skip_hubs && deg > g.hub_threshold) continue;
-        const int total = deg + (i < n_self ? 1 : 0);
-        uint32_t acc[PPL];
-#pragma unroll
-        for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
-        const bool amb = total > 0 && first_hop_minhash_fast<PPL>(g.col + rp[r], deg, total, i, a, b, acc, lane);
-        if (__any(amb)) {
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
-            first_hop_walk<PPL, true, false>(g.col + rp[r], deg, total, i, 0, 1, p, a, b, acc, nullptr, lane);
-        }
-        if (total == 0) {
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) acc[q] = 0u;
-        }
-#pragma unroll
-        for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = acc[q];
-    }
-}
-
 constexpr int kHubThreads = 1024;
 constexpr int kHubWaves = kHubThreads / kWave;
 constexpr int kHubGrid = 256;  // one workgroup per CU; workgroups beyond the hub count exit at once
@@ -365,16 +254,12 @@ int launch_first_hop(const GraphArgs &g, const uint64_t *a, const uint64_t *b, u
         hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.N + 15) / 16)), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
                            prm, hubs);
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL((first_hop_mh4_kernel<PPL>), dim3((unsigned)((g.N + 15) / 16)), dim3(256), 0, s, g, a, b, mh_out, p, hubs);
+        hipLaunchKernelGGL((first_hop_kernel<PPL, true, false>), dim3((unsigned)((g.N + 3) / 4)), dim3(256), 0, s, g, a, b, mh_out, p,
+                           (uint8_t *)nullptr, (float *)nullptr, (int64_t)0, prm, hubs);
         SS_LAUNCH_CHECK();
         return launch_first_hop_hub_only(g, a, b, PPL * kWave, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
     }
-    if (mh_out) {
-        const bool hubs = g.hub_rows && g.hub_count;
-        hipLaunchKernelGGL((first_hop_mh4_kernel<PPL>), dim3((unsigned)((g.N + 15) / 16)), dim3(256), 0, s, g, a, b, mh_out, p, hubs);
-        SS_LAUNCH_CHECK();
-        return launch_first_hop_hub_only(g, a, b, PPL * kWave, mh_out, p, nullptr, nullptr, 0, prm, s);
-    }
+    if (mh_out) return launch_first_hop_v<PPL, true, false>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
     // HLL alone: 16-lane-per-row kernel for the regular rows, the cooperative hub kernel for the rest
     const bool hubs = g.hub_rows && g.hub_count;
     hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.N + 15) / 16)), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
