@@ -159,12 +159,18 @@ __device__ __forceinline__ bool first_hop_minhash_fast(const int32_t *__restrict
         a_lo[q] = (uint32_t)a[q];
         b8[q] = (uint32_t)b[q] + 8u;
     }
+    bool seen_self = false;  // the row lists its own node explicitly (graphs that already carry self loops)
     for (int base = 0; base < total; base += kWave) {
         const int t = base + lane;
         const int64_t nid = t < deg ? (int64_t)nb[t] : self_row;
         const uint64_t hv = hash_u64((uint64_t)(nid + 1));
         const uint32_t hv_lo = (uint32_t)hv, hv_hi = (uint32_t)(hv >> 32);
-        const int cnt = total - base < kWave ? total - base : kWave;
+        int cnt = total - base < kWave ? total - base : kWave;
+        // a duplicated neighbour makes the two smallest keys collide for EVERY permutation (exact, but through the slow
+        // path); the common duplicate is an explicit self edge + the implicit self loop (slot `deg`, always the last):
+        // drop the implicit one, it adds nothing to a min
+        seen_self |= __any(t < deg && nid == self_row);
+        if (seen_self && total > deg && base + cnt == total) --cnt;
         uint32_t before[PPL];
 #pragma unroll
         for (int q = 0; q < PPL; ++q) before[q] = m1[q];
