@@ -664,7 +664,9 @@ class ElphHashes(object):
 
     def _pair_kernel(self, links, hash_table, cards, want_debug=False):
         """runs ss_pair_features for links [B,2]; returns (features [B,nf] on device, debug dict or None)"""
-        device = _compute_device(links, cards)
+        # where the links live, else where the packed tables already are, else cards, else the current device
+        first = hash_table.get(1) if hasattr(hash_table, 'get') else None
+        device = _compute_device(links, first.mh_u32 if isinstance(first, HopSketch) else None, cards)
         params = self._params(device)
         mh, hll, N, P = self._resolve_tables(hash_table, device)
         h = self.max_hops
