@@ -147,6 +147,15 @@ int ss_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
                      float *out, int32_t *dbg_match, int32_t *dbg_zero, float *dbg_inter, int32_t *err_flag,
                      void *stream);
 
+/* The same features with BUDDY's degree-normalised copy appended (next row of the scope table: replaces
+ * BUDDY._append_degree_normalised, models/elph.py:276-293, fed by HashDataset.degrees, datasets/elph.py:74).
+ *   degrees: device fp32[N];  out: device fp32 [B, 2*h(h+2)]: columns [0, h(h+2)) as ss_pair_features, columns
+ *   [h(h+2), 2h(h+2)) = feature / sqrt(degrees[u] * degrees[v]) with NaN and Inf (zero-degree nodes) replaced by 0. */
+int ss_pair_features_normalised(const int64_t *links, int64_t B, int64_t N, int32_t h,
+                                const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
+                                const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
+                                const float *degrees, float *out, int32_t *err_flag, void *stream);
+
 /* int64 <-> packed uint32 MinHash tables (the reference's tensors are int64, hashing.py:124). */
 int ss_pack_minhash(const int64_t *in, uint32_t *out, int64_t count, void *stream);
 int ss_unpack_minhash(const uint32_t *in, int64_t *out, int64_t count, void *stream);

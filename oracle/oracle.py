@@ -182,3 +182,14 @@ def pair_features(links, tables, cards, max_hops, params, use_zero_one=True, flo
                            c_int64(cards.shape[1]), ctypes.byref(params.struct), c_uint32(flags), _p(out),
                            _p(dbg.get('match')), _p(dbg.get('zeros')), _p(dbg.get('inter')), _p(dbg.get('branch')))
     return (out, dbg) if debug else out
+
+
+def append_degree_normalised(x, links, degrees):
+    """models/elph.py:276-293 on top of pair_features output: [B, nf] -> [B, 2*nf]"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    links = np.ascontiguousarray(np.asarray(links, dtype=np.int64).reshape(-1, 2))
+    degrees = np.ascontiguousarray(degrees, dtype=np.float32)
+    out = np.empty((x.shape[0], 2 * x.shape[1]), dtype=np.float32)
+    lib().so_append_degree_normalised(_p(x), c_int64(x.shape[0]), c_int32(x.shape[1]), _p(links), c_int64(degrees.shape[0]),
+                                      _p(degrees), _p(out))
+    return out

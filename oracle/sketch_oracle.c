@@ -321,3 +321,21 @@ void so_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
         free(uni);
     }
 }
+
+/* models/elph.py:276-293 BUDDY._append_degree_normalised (the first consumer of the feature rows):
+ * out[q] = [x[q], x[q] / sqrt(deg[u] * deg[v])] with NaN and Inf replaced by 0.  x: [B, nf], out: [B, 2*nf]. */
+void so_append_degree_normalised(const float *x, int64_t B, int32_t nf, const int64_t *links, int64_t N, const float *degrees,
+                                 float *out)
+{
+    for (int64_t q = 0; q < B; ++q) {
+        const int64_t u = wrap_index(links[2 * q], N), v = wrap_index(links[2 * q + 1], N);
+        const float normaliser = sqrtf(degrees[u] * degrees[v]);
+        for (int32_t k = 0; k < nf; ++k) {
+            const float f = x[q * nf + k];
+            float nrm = f / normaliser;
+            if (isnan(nrm) || isinf(nrm)) nrm = 0.0f;
+            out[q * 2 * nf + k] = f;
+            out[q * 2 * nf + nf + k] = nrm;
+        }
+    }
+}

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
                                                             int P_rt, int M_rt, const float *__restrict__ cards, int64_t cards_stride,
                                                             ss_hll_params prm, uint32_t flags, float *__restrict__ out,
                                                             int32_t *__restrict__ dbg_match, int32_t *__restrict__ dbg_zero,
-                                                            float *__restrict__ dbg_inter, int32_t *__restrict__ err)
+                                                            float *__restrict__ dbg_inter, int32_t *__restrict__ err,
+                                                            const float *__restrict__ degrees)
 {
     __shared__ EstimatorLds lds;
     const EstimatorTables est = stage_tables(lds, prm);
@@ -243,8 +244,20 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
 #pragma unroll
     for (int k = 1; k < NF; ++k) my_f = (l == k) ? f[k] : my_f;
     if (bad) my_f = __uint_as_float(0x7FC00000u);
+    if (q_ok && degrees) {
+        // fused BUDDY._append_degree_normalised (reference models/elph.py:276-293): rows become [f, f / sqrt(d_u * d_v)]
+        // with NaN / Inf (zero-degree nodes) replaced by 0
+        const float normaliser = sqrtf(degrees[u] * degrees[v]);
+        float normed = my_f / normaliser;
+        if (isnan(normed) || isinf(normed)) normed = 0.0f;
+        if (bad) normed = __uint_as_float(0x7FC00000u);
+        if (l < NF) {
+            out[q * (2 * NF) + l] = my_f;
+            out[q * (2 * NF) + NF + l] = normed;
+        }
+    }
     if (q_ok) {
-        if (l < NF) out[q * NF + l] = my_f;
+        if (l < NF && !degrees) out[q * NF + l] = my_f;
         if (l < NC) {
             if (dbg_match) dbg_match[q * NC + l] = my_match;
             if (dbg_zero) dbg_zero[q * NC + l] = my_zeros;
@@ -257,12 +270,12 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
 template <int H, int TP, int TM>
 int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &tabs, int P, int M, const float *cards,
                  int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *dbg_match,
-                 int32_t *dbg_zero, float *dbg_inter, int32_t *err, hipStream_t stream)
+                 int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream)
 {
     const int pairs_per_block = 256 / kRow;
     const int64_t blocks = (B + pairs_per_block - 1) / pairs_per_block;
     hipLaunchKernelGGL((pair_features_kernel<H, TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, links, B, N, tabs, P, M,
-                       cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err);
+                       cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
@@ -270,30 +283,29 @@ int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &t
 template <int H>
 int dispatch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &tabs, int P, int M, const float *cards,
                    int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *dbg_match,
-                   int32_t *dbg_zero, float *dbg_inter, int32_t *err, hipStream_t stream)
+                   int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream)
 {
     if (P == 128 && M == 256)
         return launch_pairs<H, 128, 256>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero,
-                                         dbg_inter, err, stream);
+                                         dbg_inter, err, degrees, stream);
     return launch_pairs<H, 0, 0>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter,
-                                 err, stream);
+                                 err, degrees, stream);
 }
 
 }  // namespace ss
 
-extern "C" int ss_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
-                                const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
-                                const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
-                                float *out, int32_t *dbg_match, int32_t *dbg_zero, float *dbg_inter, int32_t *err_flag,
-                                void *stream)
+static int pair_features_impl(const int64_t *links, int64_t B, int64_t N, int32_t h, const uint32_t *const *mh, int32_t P,
+                              const uint8_t *const *hll, const float *cards, int64_t cards_stride, const ss_hll_params *prm,
+                              uint32_t flags, const float *degrees, float *out, int32_t *dbg_match, int32_t *dbg_zero,
+                              float *dbg_inter, int32_t *err_flag, void *stream)
 {
     using namespace ss;
     if (h < 1 || h > SS_MAX_HOPS) return SS_ERR_UNSUPPORTED;  // hashing.py:54, 308-309
-    if (B < 0 || N <= 0) return B == 0 && N >= 0 ? SS_OK : SS_ERR_INVALID_ARG;
+    if (B < 0 || N < 0) return SS_ERR_INVALID_ARG;
     const int rc = check_params(prm);
     if (rc != SS_OK) return rc;
     if (B == 0) return SS_OK;
-    if (!links || !mh || !hll || !cards || !out || cards_stride < h) return SS_ERR_INVALID_ARG;
+    if (N == 0 || !links || !mh || !hll || !cards || !out || cards_stride < h) return SS_ERR_INVALID_ARG;
     if (P <= 0 || (P & 3) || P > 2048) return SS_ERR_INVALID_ARG;
     PairTables tabs = {};
     for (int k = 0; k < h; ++k) {
@@ -304,8 +316,28 @@ extern "C" int ss_pair_features(const int64_t *links, int64_t B, int64_t N, int3
     const int M = 1 << prm->p;
     hipStream_t s = (hipStream_t)stream;
     switch (h) {
-        case 1: return dispatch_pairs<1>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, s);
-        case 2: return dispatch_pairs<2>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, s);
-        default: return dispatch_pairs<3>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, s);
+        case 1: return dispatch_pairs<1>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s);
+        case 2: return dispatch_pairs<2>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s);
+        default: return dispatch_pairs<3>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s);
     }
+}
+
+extern "C" int ss_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
+                                const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
+                                const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
+                                float *out, int32_t *dbg_match, int32_t *dbg_zero, float *dbg_inter, int32_t *err_flag,
+                                void *stream)
+{
+    return pair_features_impl(links, B, N, h, mh, P, hll, cards, cards_stride, prm, flags, nullptr, out, dbg_match, dbg_zero,
+                              dbg_inter, err_flag, stream);
+}
+
+extern "C" int ss_pair_features_normalised(const int64_t *links, int64_t B, int64_t N, int32_t h,
+                                           const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
+                                           const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
+                                           const float *degrees, float *out, int32_t *err_flag, void *stream)
+{
+    if (!degrees) return SS_ERR_INVALID_ARG;
+    return pair_features_impl(links, B, N, h, mh, P, hll, cards, cards_stride, prm, flags, degrees, out, nullptr, nullptr, nullptr,
+                              err_flag, stream);
 }

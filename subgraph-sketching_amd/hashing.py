@@ -662,8 +662,8 @@ class ElphHashes(object):
                 raise ValueError('hash tables of different hops must have the same shape')
         return mh, hll, N, P
 
-    def _pair_kernel(self, links, hash_table, cards, want_debug=False):
-        """runs ss_pair_features for links [B,2]; returns (features [B,nf] on device, debug dict or None)"""
+    def _pair_kernel(self, links, hash_table, cards, want_debug=False, degrees=None):
+        """runs ss_pair_features for links [B,2]; returns (features [B,nf] (or [B,2nf] with degrees) on device, debug dict or None)"""
         # where the links live, else where the packed tables already are, else cards, else the current device
         first = hash_table.get(1) if hasattr(hash_table, 'get') else None
         device = _compute_device(links, first.mh_u32 if isinstance(first, HopSketch) else None, cards)
@@ -690,16 +690,28 @@ class ElphHashes(object):
             if cd.stride(1) != 1:
                 cd = cd.contiguous()
         nf = h * (h + 2)
+        mh_ptrs = (c_void_p * h)(*[t.data_ptr() for t in mh])
+        hll_ptrs = (c_void_p * h)(*[t.data_ptr() for t in hll])
+        flags = (_native.SS_FLAG_USE_ZERO_ONE if self.use_zero_one else 0) | (_native.SS_FLAG_FLOOR_SF if self.floor_sf else 0)
+        err = _error_flag(device)
+        if degrees is not None:
+            dg = degrees.to(device=device, dtype=torch.float32).contiguous()
+            if dg.dim() != 1 or dg.numel() != N:
+                raise ValueError(f'degrees must have shape [{N}], got {tuple(dg.shape)}')
+            out = torch.empty((B, 2 * nf), dtype=torch.float32, device=device)
+            with _Span('pair_features', device):
+                _native.check(_native.lib().ss_pair_features_normalised(
+                    _ptr(lk), B, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0), byref(params.struct), flags, _ptr(dg),
+                    _ptr(out), _ptr(err), _stream(device)), 'ss_pair_features_normalised')
+            if self.strict_bounds and B > 0 and _take_error(device):
+                raise IndexError(f'links refer to nodes outside [-{N}, {N})')
+            return out, None
         out = torch.empty((B, nf), dtype=torch.float32, device=device)
         dbg = None
-        err = _error_flag(device)
         if want_debug:
             dbg = {'match': torch.empty((B, h, h), dtype=torch.int32, device=device),
                    'zeros': torch.empty((B, h, h), dtype=torch.int32, device=device),
                    'inter': torch.empty((B, h, h), dtype=torch.float32, device=device)}
-        mh_ptrs = (c_void_p * h)(*[t.data_ptr() for t in mh])
-        hll_ptrs = (c_void_p * h)(*[t.data_ptr() for t in hll])
-        flags = (_native.SS_FLAG_USE_ZERO_ONE if self.use_zero_one else 0) | (_native.SS_FLAG_FLOOR_SF if self.floor_sf else 0)
         with _Span('pair_features', device):
             _native.check(_native.lib().ss_pair_features(
                 _ptr(lk), B, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0), byref(params.struct), flags, _ptr(out),
@@ -776,13 +788,16 @@ class ElphHashes(object):
             raise ValueError('source and destination hash value shapes must be the same')
         return torch.count_nonzero(src == dst, dim=-1) / self.num_perm
 
-    def get_subgraph_features(self, links, hash_table, cards, batch_size=11000000):
+    def get_subgraph_features(self, links, hash_table, cards, batch_size=11000000, degrees=None):
         """structural features of node pairs: approximations of the number of nodes at distance (d_u, d_v)
         from (u, v), for the (d_u, d_v) listed in LABEL_LOOKUP[max_hops] (reference :258-323).
         @param links: int tensor [n_edges, 2] (or [2])
         @param hash_table: {hop: {'hll': [N, m], 'minhash': [N, num_perm]}} (a SketchTable or plain tensors)
         @param cards: float tensor [N, max_hops] of neighbourhood cardinality estimates
         @param batch_size: pairs per kernel launch (results do not depend on it)
+        @param degrees: optional float tensor [N] (HashDataset.degrees, datasets/elph.py:74).  Extension beyond the
+               reference signature: when given, BUDDY's degree-normalised copy (models/elph.py:276-293: feature /
+               sqrt(d_u * d_v), NaN / Inf -> 0) is appended in the same kernel and the result is [n_edges, 2 * F].
         @return: float32 [n_edges, max_hops * (max_hops + 2)] on links.device"""
         if self.max_hops not in (1, 2, 3):
             raise NotImplementedError("Only 1, 2 and 3 hop hashes are implemented")
@@ -790,8 +805,9 @@ class ElphHashes(object):
             links = links.unsqueeze(0)
         n = links.size(0)
         if n <= batch_size:
-            feats, _ = self._pair_kernel(links, hash_table, cards)
+            feats, _ = self._pair_kernel(links, hash_table, cards, degrees=degrees)
         else:
-            chunks = [self._pair_kernel(links[s:s + batch_size], hash_table, cards)[0] for s in range(0, n, batch_size)]
+            chunks = [self._pair_kernel(links[s:s + batch_size], hash_table, cards, degrees=degrees)[0]
+                      for s in range(0, n, batch_size)]
             feats = torch.cat(chunks, dim=0)
         return feats if feats.device == links.device else feats.to(links.device)

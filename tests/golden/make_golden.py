@@ -114,6 +114,29 @@ def load_reference(nan_bias=False):
     return mod, asl
 
 
+def load_reference_buddy():
+    """the reference's BUDDY class (src/models/elph.py); its module imports PyG layers that are absent here and unused by
+    the one static-like method we call, so they are stood in for by empty classes"""
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith('__'):
+                raise AttributeError(name)
+            return type(name, (object,), {})
+    for name in ('torch_geometric.nn.conv', 'torch_geometric.nn.conv.gcn_conv', 'torch_geometric.nn.dense',
+                 'torch_geometric.nn.dense.linear', 'torch_geometric.nn.models', 'torch_geometric.nn.inits', 'torch_sparse',
+                 'torch_scatter', 'torch_geometric.data', 'torch_geometric.typing'):
+        sys.modules.setdefault(name, _Any(name))
+    tgnn = sys.modules['torch_geometric.nn']
+    for name in ('GCNConv', 'SAGEConv', 'global_mean_pool', 'global_sort_pool', 'global_add_pool', 'global_max_pool', 'GINConv',
+                 'MLP', 'TransformerConv', 'GATConv'):
+        if not hasattr(tgnn, name):
+            setattr(tgnn, name, type(name, (object,), {}))
+    if '/root/reference' not in sys.path:
+        sys.path.insert(0, '/root/reference')
+    import src.models.elph as ref_models
+    return ref_models.BUDDY
+
+
 def args(h=2, p=8, P=128, floor_sf=False, use_zero_one=True):
     return Namespace(max_hash_hops=h, hll_p=p, minhash_num_perm=P, floor_sf=floor_sf, use_zero_one=use_zero_one)
 
@@ -219,6 +242,17 @@ def main():
     # written by the reference's objects themselves: the --load_hashes compatibility fixture
     torch.save({k: tables[k] for k in range(3)}, os.path.join(HERE, 'ref_ba40_hashcache.pt'))
     torch.save(cards[:, :2].clone(), os.path.join(HERE, 'ref_ba40_cardcache.pt'))
+
+    # ---- G9: BUDDY's degree-normalised copy (models/elph.py:276-293), computed by the reference's own method -----------
+    buddy = load_reference_buddy()
+    deg = np.bincount(ei[1], minlength=n).astype(np.float32)   # HashDataset.degrees = A.sum(axis=0) (datasets/elph.py:74)
+    deg[[3, 17]] = 0.0                                         # zero-degree nodes exercise the NaN / Inf -> 0 rule
+    g9 = {'degrees': deg, 'links': links.numpy()}
+    for h in (1, 2, 3):
+        sf = torch.from_numpy(g[f'feat_h{h}_zo1_fl0'])
+        d = torch.from_numpy(deg)
+        g9[f'normed_h{h}'] = buddy._append_degree_normalised(None, sf, d[links[:, 0]], d[links[:, 1]]).numpy()
+    np.savez_compressed(os.path.join(HERE, 'g9_degree_normalised.npz'), **g9)
 
     # ---- G3b: other (p, P) parameterisations on the same graph ------------------------------
     g = {'edge_index': ei, 'num_nodes': np.asarray(n), 'links': links.numpy()}

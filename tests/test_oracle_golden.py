@@ -194,3 +194,15 @@ def test_reference_style_torch_path_matches_oracle(regenerated_tables):
     for k1 in (1, 2):
         for k2 in (1, 2):
             np.testing.assert_allclose(inter[(k1, k2)].numpy(), dbg['inter'][:, k1 - 1, k2 - 1], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('h', [1, 2, 3])
+def test_degree_normalised_features_vs_reference(h):
+    """BUDDY._append_degree_normalised (models/elph.py:276-293) as computed by the reference's own method"""
+    g = load_golden('g9_degree_normalised.npz')
+    base = load_golden('g3_g4_ba40.npz')[f'feat_h{h}_zo1_fl0']
+    got = oracle.append_degree_normalised(base, g['links'], g['degrees'])
+    assert got.shape == (len(base), 2 * base.shape[1])
+    assert np.array_equal(got, g[f'normed_h{h}']), 'sqrt / divide / NaN-Inf rule must be bit-exact'
+    zero_rows = (g['degrees'][g['links'][:, 0]] == 0) | (g['degrees'][g['links'][:, 1]] == 0)
+    assert zero_rows.any() and not got[zero_rows][:, base.shape[1]:].any()
