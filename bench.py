@@ -151,6 +151,9 @@ def main():
                          'elph: the exact call sequence of ELPH.forward (models/elph.py:186-213) + one query per step; '
                          'buddy: one build amortised over --buddy-batches query batches (datasets/elph.py:200-208)')
     ap.add_argument('--buddy-batches', type=int, default=40)
+    ap.add_argument('--build', default='replicated', choices=['replicated', 'sharded'],
+                    help='N > 1 only. replicated (default): every rank builds the whole table; sharded: destination rows split '
+                         'across ranks + in-place all-gather after every hop (pays off at ogbl-ppa / citation2 sizes)')
     ap.add_argument('--time-all-kernels', action='store_true', help='HIP-event spans around every launch (default: only the roofline kernel)')
     a = ap.parse_args()
     global N_NODES, E_UND, H, BATCH, GRAPH_KIND, PL_ALPHA
@@ -182,8 +185,15 @@ def main():
     links = torch.from_numpy(links_np).to(dev)
     gathered = torch.empty((world * BATCH, H * (H + 2)), dtype=torch.float32, device=dev) if launched else None
 
+    sharded_build = launched and world > 1 and a.build == 'sharded'
+
+    def build_tables():
+        if sharded_build:
+            return ssa.dist.sharded_build_hash_tables(eh, N_NODES, ei)
+        return eh.build_hash_tables(N_NODES, ei)
+
     def step_build_query():
-        table, cards = eh.build_hash_tables(N_NODES, ei)
+        table, cards = build_tables()
         f = eh.get_subgraph_features(links, table, cards)
         if launched:
             dist.all_gather_into_tensor(gathered, f)
@@ -210,7 +220,7 @@ def main():
 
     def step_buddy():
         """one build, then --buddy-batches batches of B pairs; a 'step' is one batch incl. its share of the build"""
-        table, cards = eh.build_hash_tables(N_NODES, ei)
+        table, cards = build_tables()
         for _ in range(a.buddy_batches):
             f = eh.get_subgraph_features(links, table, cards)
             if launched:
@@ -260,6 +270,9 @@ def main():
         prop_ms, prop_n = dom_ms.value, dom_n.value
         prop_bytes = (e_prime + N_NODES) * 4 * P + 4 * e_prime + 8 * (N_NODES + 1)
         roof_kernel = 'ss::propagate_kernel<128,256> (MinHash table hop: (E\'+N)*4P + 4E\' + 8(N+1) bytes)'
+        if sharded_build:  # each launch covers this rank's N/G destination rows and (on the uniform graph) E'/G in-edges
+            prop_bytes //= world
+            roof_kernel += f' / {world} ranks (row-sharded build)'
     pair_bytes = BATCH * (2 * H * ROW_BYTES + 16 + 8 * H + 4 * H * (H + 2))
     traffic = None
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -277,7 +290,9 @@ def main():
                                ('' if a.api == 'build_query' else f' [api mode: {a.api}]'),
                    'num_nodes': N_NODES, 'directed_edges': 2 * E_UND, 'max_hash_hops': H, 'minhash_num_perm': P, 'hll_p': HLL_P,
                    'pairs_per_step_per_gpu': pairs_per_step, 'global_pairs_per_step': world * pairs_per_step,
-                   'parallelism': f'edge-batch sharded x{world}, sketch table replicated, all_gather of features',
+                   'parallelism': f'edge-batch sharded x{world}, all_gather of features; sketch table ' +
+                                  (f'built row-sharded x{world} with an in-place all_gather per hop and sketch' if sharded_build
+                                   else 'replicated (every rank builds it)'),
                    'hll_tables': eh.hll_tables.provenance},
         'roofline': {'kernel': roof_kernel + ('' if H > 1 else ' (not launched at h=1)') +
                                (' [elph api mode launches it per sketch: the bytes model below does not apply]' if a.api == 'elph' else ''), 'bound': 'hbm', 'achieved': prop_bytes / (prop_ms * 1e-3) / 1e9 if prop_ms else None,

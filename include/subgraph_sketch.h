@@ -84,6 +84,9 @@ typedef struct ss_csr_graph {
     int32_t reserved;
     const int32_t *hub_rows;          /* ... listed here (device int32[*hub_count], nullable) and processed by  */
     const int32_t *hub_count;         /* a 16-wave cooperative kernel instead of a single wavefront             */
+    int64_t row_begin;                /* destination rows [row_begin, row_end) are computed by ss_propagate /    */
+    int64_t row_end;                  /* ss_first_hop (multi-GPU destination-range sharding);       */
+                                      /* row_end == 0 means all rows.  Outputs are indexed by the GLOBAL row id.  */
 } ss_csr_graph;
 
 /* CSR-by-destination of an edge list.  Replaces the message materialisation of

@@ -27,7 +27,7 @@ class CsrGraphStruct(ctypes.Structure):
     """mirror of `struct ss_csr_graph`"""
     _fields_ = [('rowptr', c_void_p), ('col', c_void_p), ('num_nodes', c_int64), ('n_self_loops', c_int64),
                 ('n_self_loops_dev', c_void_p), ('hub_threshold', c_int32), ('reserved', c_int32),
-                ('hub_rows', c_void_p), ('hub_count', c_void_p)]
+                ('hub_rows', c_void_p), ('hub_count', c_void_p), ('row_begin', c_int64), ('row_end', c_int64)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/subgraph_sketch.h

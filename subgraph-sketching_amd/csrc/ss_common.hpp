@@ -213,11 +213,22 @@ struct GraphArgs {  // device-side view of ss_csr_graph
     int hub_threshold;
     const int32_t *hub_rows;
     const int32_t *hub_count;
+    int64_t row0, row1;  // destination rows [row0, row1) are computed by this launch
+    __host__ __device__ int64_t rows() const { return row1 - row0; }
+    __device__ bool owns(int64_t i) const { return i >= row0 && i < row1; }
 };
 
 inline GraphArgs to_args(const ss_csr_graph &g)
 {
-    return GraphArgs{g.rowptr, g.col, g.num_nodes, g.n_self_loops, g.n_self_loops_dev, g.hub_threshold, g.hub_rows, g.hub_count};
+    const bool all = g.row_end == 0 && g.row_begin == 0;
+    return GraphArgs{g.rowptr, g.col, g.num_nodes, g.n_self_loops, g.n_self_loops_dev, g.hub_threshold, g.hub_rows, g.hub_count,
+                     all ? 0 : g.row_begin, all ? g.num_nodes : g.row_end};
+}
+
+inline bool row_range_ok(const ss_csr_graph &g)
+{
+    if (g.row_end == 0 && g.row_begin == 0) return true;
+    return g.row_begin >= 0 && g.row_begin <= g.row_end && g.row_end <= g.num_nodes;
 }
 
 inline int check_params(const ss_hll_params *prm)

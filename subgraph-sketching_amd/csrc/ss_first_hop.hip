@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
     constexpr int P = PPL * kWave;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + wave;
-    if (i >= g.N) return;
+    const int64_t i = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kWave) + wave;
+    if (i >= g.row1) return;
     const int64_t rb = g.rowptr[i];
     const int deg = (int)(g.rowptr[i + 1] - rb);
     if (skip_hubs && deg > g.hub_threshold) return;  // left to first_hop_hub_kernel
@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
     if (want_cards) est = stage_tables(lds, prm);
     const int l = threadIdx.x & (kRow - 1);
     const int grp = threadIdx.x / kRow;
-    const int64_t i_raw = (int64_t)blockIdx.x * (blockDim.x / kRow) + grp;
-    const bool ok = i_raw < g.N;
-    const int64_t i = ok ? i_raw : g.N - 1;
+    const int64_t i_raw = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kRow) + grp;
+    const bool ok = i_raw < g.row1;
+    const int64_t i = ok ? i_raw : g.row1 - 1;
     uint32_t *row = rows[grp];
 #pragma unroll
     for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4 *>(row + 64 * k + 4 * l) = u32x4{0u, 0u, 0u, 0u};
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
     for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
         const int64_t i = g.hub_rows[h];
+        if (!g.owns(i)) continue;  // workgroup-uniform
         const int64_t rb = g.rowptr[i];
         const int deg = (int)(g.rowptr[i + 1] - rb);
         const int total = deg + (i < n_self ? 1 : 0);
@@ -230,7 +231,7 @@ template <int PPL, bool DO_MH, bool DO_HLL>
 int launch_first_hop_v(const GraphArgs &g, const uint64_t *a, const uint64_t *b, uint32_t *mh_out, int p, uint8_t *hll_out,
                        float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t s)
 {
-    const int64_t blocks = (g.N + 3) / 4;
+    const int64_t blocks = (g.rows() + 3) / 4;
     const bool hubs = g.hub_rows && g.hub_count;
     hipLaunchKernelGGL((first_hop_kernel<PPL, DO_MH, DO_HLL>), dim3((unsigned)blocks), dim3(256), 0, s, g, a, b, mh_out, p, hll_out,
                        cards_out, cards_stride, prm, hubs);
@@ -251,10 +252,10 @@ int launch_first_hop(const GraphArgs &g, const uint64_t *a, const uint64_t *b, u
         // both sketches: the latency-optimised HLL kernel + the MinHash kernel beat the combined kernel (37 + 134 us vs
         // 184 us on the bench graph); one hub pass serves both
         const bool hubs = g.hub_rows && g.hub_count;
-        hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.N + 15) / 16)), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
+        hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 15) / 16)), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
                            prm, hubs);
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL((first_hop_kernel<PPL, true, false>), dim3((unsigned)((g.N + 3) / 4)), dim3(256), 0, s, g, a, b, mh_out, p,
+        hipLaunchKernelGGL((first_hop_kernel<PPL, true, false>), dim3((unsigned)((g.rows() + 3) / 4)), dim3(256), 0, s, g, a, b, mh_out, p,
                            (uint8_t *)nullptr, (float *)nullptr, (int64_t)0, prm, hubs);
         SS_LAUNCH_CHECK();
         return launch_first_hop_hub_only(g, a, b, PPL * kWave, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
@@ -262,7 +263,7 @@ int launch_first_hop(const GraphArgs &g, const uint64_t *a, const uint64_t *b, u
     if (mh_out) return launch_first_hop_v<PPL, true, false>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
     // HLL alone: 16-lane-per-row kernel for the regular rows, the cooperative hub kernel for the rest
     const bool hubs = g.hub_rows && g.hub_count;
-    hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.N + 15) / 16)), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
+    hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 15) / 16)), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
                        prm, hubs);
     SS_LAUNCH_CHECK();
     if (hubs) {
@@ -323,7 +324,9 @@ extern "C" int ss_first_hop(const ss_csr_graph *graph, const uint64_t *a, const 
         if (prm->p != p) return SS_ERR_INVALID_ARG;
         p0 = *prm;
     }
+    if (!row_range_ok(*graph)) return SS_ERR_INVALID_ARG;
     const GraphArgs g = to_args(*graph);
+    if (g.rows() == 0) return SS_OK;
     hipStream_t s = (hipStream_t)stream;
     switch (P / kWave) {
         case 1: return launch_first_hop<1>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, p0, s);

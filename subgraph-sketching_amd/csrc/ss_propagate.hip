@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
     const int M = TM ? TM : M_rt;
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform row id (readfirstlane makes the uniformity visible to the compiler: scalar loads, scalar loop control)
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    if (i >= g.N) return;
+    const int64_t i = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    if (i >= g.row1) return;
 
     const int64_t rb = g.rowptr[i];
     const int deg = (int)(g.rowptr[i + 1] - rb);
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void hll_propagate_row16_kernel(GraphArgs g, c
     const bool want_cards = cards_out != nullptr;
     EstimatorTables est;
     if (want_cards) est = stage_tables(lds, prm);
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / kRow) + threadIdx.x / kRow;
-    hll_hop_row16(g, row < g.N ? row : -1, skip_hubs, hll_in, hll_out, cards_out, cards_stride, est, want_cards, threadIdx.x & (kRow - 1));
+    const int64_t row = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kRow) + threadIdx.x / kRow;
+    hll_hop_row16(g, row < g.row1 ? row : -1, skip_hubs, hll_in, hll_out, cards_out, cards_stride, est, want_cards, threadIdx.x & (kRow - 1));
 }
 
 // ---- hub rows: one 1024-thread workgroup (16 wavefronts) per row; P = 128, M = 256 only -------------------------
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
 
     for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
         const int64_t i = g.hub_rows[h];
+        if (!g.owns(i)) continue;  // workgroup-uniform
         const int64_t rb = g.rowptr[i];
         const int deg = (int)(g.rowptr[i + 1] - rb);
         const int total = deg + (i < n_self ? 1 : 0);
@@ -195,9 +196,9 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_profile_events;
 struct ProfileSpan {
     hipEvent_t start = nullptr, stop = nullptr;
     hipStream_t stream;
-    explicit ProfileSpan(hipStream_t s) : stream(s)
+    explicit ProfileSpan(hipStream_t s, bool wanted = true) : stream(s)
     {
-        if (!g_profile_on) return;
+        if (!g_profile_on || !wanted) return;
         if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) { start = nullptr; return; }
         (void)hipEventRecord(start, stream);
     }
@@ -214,10 +215,13 @@ int launch_propagate(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out
                      float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
 {
     const int rows_per_block = 256 / kWave;
-    const int64_t blocks = (g.N + rows_per_block - 1) / rows_per_block;
+    const int64_t blocks = (g.rows() + rows_per_block - 1) / rows_per_block;
     const bool hubs = TP == 128 && TM == 256 && g.hub_rows && g.hub_count;
-    hipLaunchKernelGGL((propagate_kernel<TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, g, mh_in, mh_out, P, hll_in, hll_out, M,
-                       cards_out, cards_stride, prm, hubs);
+    {
+        ProfileSpan span(stream, mh_out && !hll_out && TP == 128);  // MinHash table hop
+        hipLaunchKernelGGL((propagate_kernel<TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, g, mh_in, mh_out, P, hll_in, hll_out,
+                           M, cards_out, cards_stride, prm, hubs);
+    }
     SS_LAUNCH_CHECK();
     if (hubs) {
         hipLaunchKernelGGL(propagate_hub_kernel, dim3(kHubGrid), dim3(kHubThreads), 0, stream, g, mh_in, mh_out, hll_in, hll_out,
@@ -247,6 +251,7 @@ extern "C" int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, ui
     if (!graph || graph->num_nodes < 0 || !graph->rowptr) return SS_ERR_INVALID_ARG;
     const int64_t N = graph->num_nodes;
     if (N == 0) return SS_OK;
+    if (!row_range_ok(*graph)) return SS_ERR_INVALID_ARG;
     if ((mh_in == nullptr) != (mh_out == nullptr) || (hll_in == nullptr) != (hll_out == nullptr)) return SS_ERR_INVALID_ARG;
     if (!mh_out && !hll_out) return SS_ERR_INVALID_ARG;
     if (mh_out && (P <= 0 || (P & 3) || P > 2048)) return SS_ERR_INVALID_ARG;
@@ -262,9 +267,11 @@ extern "C" int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, ui
         p0 = *prm;
     }
     const GraphArgs g = to_args(*graph);
+    if (g.rows() == 0) return SS_OK;
+    const int64_t R = g.rows();
     if (!mh_out && M == 256) {  // HLL alone: 4 destinations per wavefront
         const bool hubs = g.hub_rows && g.hub_count;
-        hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, g, hll_in, hll_out,
+        hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, g, hll_in, hll_out,
                            cards_out, cards_stride, p0, hubs);
         SS_LAUNCH_CHECK();
         return launch_propagate_hub_only(g, nullptr, nullptr, hll_in, hll_out, cards_out, cards_stride, p0, (hipStream_t)stream);
@@ -274,12 +281,12 @@ extern "C" int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, ui
         // graph): the HLL kernel keeps 4 destinations in flight per wavefront, the MinHash kernel one; a single hub pass
         // serves both
         const bool hubs = g.hub_rows && g.hub_count;
-        hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, g, hll_in, hll_out,
+        hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, g, hll_in, hll_out,
                            cards_out, cards_stride, p0, hubs);
         SS_LAUNCH_CHECK();
         {
             ProfileSpan span((hipStream_t)stream);
-            hipLaunchKernelGGL((propagate_kernel<128, 256>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, mh_in,
+            hipLaunchKernelGGL((propagate_kernel<128, 256>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, mh_in,
                                mh_out, 128, (const uint8_t *)nullptr, (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, p0, hubs);
         }
         SS_LAUNCH_CHECK();

@@ -311,12 +311,16 @@ class CsrGraph(object):
         self.hub_rows, self.hub_count, self.hub_threshold = hub_rows, hub_count, hub_threshold
         self.use_inferred_self_loops = False
 
-    def struct(self):
+    def struct(self, rows=None):
+        """rows = (begin, end): only those destination rows are computed (multi-GPU destination-range sharding)"""
+        begin, end = (0, 0) if rows is None else rows
+        if rows is not None and end == 0:  # (0, 0) would mean "all rows" to the library: express the empty range at N
+            begin = end = self.num_nodes
         return _native.CsrGraphStruct(rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(), num_nodes=self.num_nodes,
                                       n_self_loops=0,
                                       n_self_loops_dev=self.n_self_dev.data_ptr() if self.use_inferred_self_loops else None,
                                       hub_threshold=self.hub_threshold, reserved=0, hub_rows=self.hub_rows.data_ptr(),
-                                      hub_count=self.hub_count.data_ptr())
+                                      hub_count=self.hub_count.data_ptr(), row_begin=begin, row_end=end)
 
 
 def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
@@ -370,8 +374,9 @@ class _CsrCache(object):
 _default_csr_cache = _CsrCache()
 
 
-def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, params=None, mh_out=None, hll_out=None):
-    """one hop; returns (mh_out or None, hll_out or None).  mh_in packed int32 [N,P], hll_in uint8 [N,M]"""
+def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, params=None, mh_out=None, hll_out=None, rows=None):
+    """one hop; returns (mh_out or None, hll_out or None).  mh_in packed int32 [N,P], hll_in uint8 [N,M];
+    rows = (begin, end) restricts the destination rows written (inputs are always the full tables)"""
     N = csr.num_nodes
     if mh_in is not None and mh_out is None:
         mh_out = torch.empty_like(mh_in)
@@ -380,7 +385,7 @@ def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, param
     P = mh_in.size(1) if mh_in is not None else 0
     M = hll_in.size(1) if hll_in is not None else 0
     prm = byref(params.struct) if params is not None else None
-    graph = csr.struct()
+    graph = csr.struct(rows)
     with _Span('propagate' if (mh_in is not None and hll_in is not None) else ('propagate_mh' if hll_in is None else 'propagate_hll'), device):
         _native.check(_native.lib().ss_propagate(byref(graph), _ptr(mh_in), _ptr(mh_out), P, _ptr(hll_in), _ptr(hll_out), M,
                                                  _ptr(cards_out), cards_stride, prm, _stream(device)), 'ss_propagate')
@@ -599,6 +604,13 @@ class ElphHashes(object):
     def build_hash_tables(self, num_nodes, edge_index):
         """k-hop sketches of every node, k = 0..max_hops, and their HLL cardinalities (reference :139-165).
         @return: (SketchTable {k: {'hll','minhash'}}, cards float32 [num_nodes, max_hops])"""
+        return self._build(num_nodes, edge_index, None)
+
+    def _build(self, num_nodes, edge_index, shard):
+        """shard = None: this process computes every row.  Otherwise (dist.sharded_build_hash_tables) an object with
+        `rows` = (begin, end) owned by this rank, `padded_rows` >= num_nodes (allocation size, a multiple of the world
+        size) and `gather(tensor) -> handle` / `wait(handle)`: in-place all-gather of the owned row blocks.  The two
+        sketches are launched separately so that the gather of one overlaps the kernel of the other."""
         home = edge_index.device
         device = _compute_device(edge_index)
         params = self._params(device)
@@ -606,39 +618,64 @@ class ElphHashes(object):
         # produced on the device by ss_csr_build and read by the propagation kernel -- no host round trip
         csr = build_csr(edge_index, num_nodes, device, check=self.strict_bounds)
         csr.use_inferred_self_loops = True
-        cards = torch.empty((num_nodes, self.max_hops), dtype=torch.float32, device=device)
+        rows = None if shard is None else shard.rows
+        n_alloc = num_nodes if shard is None else shard.padded_rows
+        cards = torch.empty((n_alloc, self.max_hops), dtype=torch.float32, device=device)
         table = SketchTable()
         h = self.max_hops
         fused = self.fuse_first_hop and self.p == 8 and self.num_perm % 64 == 0 and self.num_perm <= 256
+        mh = [torch.empty((n_alloc, self.num_perm), dtype=torch.int32, device=device) for _ in range(h)]
+        hll = [torch.empty((n_alloc, self.m), dtype=torch.uint8, device=device) for _ in range(h)]
         if fused:
             # hop 1 is computed straight from node ids (ss_first_hop); the hop-0 tables (pure functions of the node id,
             # never read by get_subgraph_features) are produced only if a caller actually looks at them
             table[0] = HopSketch(None, None, home, make_packed=lambda n=num_nodes, d=device: (self._init_minhash_u32(n, d),
                                                                                             self._init_hll_u8(n, d)))
-            mh = [torch.empty((num_nodes, self.num_perm), dtype=torch.int32, device=device) for _ in range(h)]
-            hll = [torch.empty((num_nodes, self.m), dtype=torch.uint8, device=device) for _ in range(h)]
+            mh_prev = hll_prev = None
+        else:
+            mh_prev = self._init_minhash_u32(num_nodes, device)  # hop 0 is replicated: a pure function of the node id
+            hll_prev = self._init_hll_u8(num_nodes, device)
+            table[0] = HopSketch(mh_prev, hll_prev, home)
+        if shard is None:
             # (inside the library each of these calls is one launch per sketch + one hub pass: measured faster than
             # two-sketch kernels -- first hop 37 + 134 us vs 184, table hop 111 + 192 us vs 326 on the bench graph)
-            self._first_hop(csr, device, mh[0], hll[0], cards, params)
-            for k in range(2, h + 1):
-                _propagate(csr, mh[k - 2], hll[k - 2], device, cards_out=cards[:, k - 1], cards_stride=h, params=params,
-                           mh_out=mh[k - 1], hll_out=hll[k - 1])
             for k in range(1, h + 1):
-                table[k] = HopSketch(mh[k - 1], hll[k - 1], home)
+                if k == 1 and fused:
+                    self._first_hop(csr, device, mh[0], hll[0], cards, params)
+                else:
+                    logger.info(f"Calculating hop {k} hashes")
+                    _propagate(csr, mh_prev, hll_prev, device, cards_out=cards[:, k - 1], cards_stride=h, params=params,
+                               mh_out=mh[k - 1], hll_out=hll[k - 1])
+                mh_prev, hll_prev = mh[k - 1], hll[k - 1]
         else:
-            mh_k = self._init_minhash_u32(num_nodes, device)
-            hll_k = self._init_hll_u8(num_nodes, device)
-            table[0] = HopSketch(mh_k, hll_k, home)
+            pending_mh = pending_hll = None
             for k in range(1, h + 1):
-                logger.info(f"Calculating hop {k} hashes")
-                mh_k, hll_k = _propagate(csr, mh_k, hll_k, device, cards_out=cards[:, k - 1], cards_stride=h, params=params)
-                table[k] = HopSketch(mh_k, hll_k, home)
+                shard.wait(pending_mh)  # hop k-1 MinHash rows of every rank have arrived
+                if k == 1 and fused:
+                    self._first_hop(csr, device, mh[0], None, None, params, rows=rows)
+                else:
+                    _propagate(csr, mh_prev, None, device, mh_out=mh[k - 1], rows=rows)
+                pending_mh = shard.gather(mh[k - 1])
+                shard.wait(pending_hll)
+                if k == 1 and fused:
+                    self._first_hop(csr, device, None, hll[0], cards, params, rows=rows)
+                else:
+                    _propagate(csr, None, hll_prev, device, cards_out=cards[:, k - 1], cards_stride=h, params=params,
+                               hll_out=hll[k - 1], rows=rows)
+                pending_hll = shard.gather(hll[k - 1])
+                mh_prev, hll_prev = mh[k - 1], hll[k - 1]
+            shard.wait(pending_mh)
+            shard.wait(pending_hll)
+            shard.wait(shard.gather(cards))
+            cards = cards[:num_nodes]
+        for k in range(1, h + 1):
+            table[k] = HopSketch(mh[k - 1][:num_nodes], hll[k - 1][:num_nodes], home)
         return table, (cards if home == device else cards.to(home))
 
-    def _first_hop(self, csr, device, mh_out, hll_out, cards, params):
+    def _first_hop(self, csr, device, mh_out, hll_out, cards, params, rows=None):
         """fused hop-0 + hop-1 (ss_first_hop) for either or both sketches"""
         ab = self._perms(device)
-        graph = csr.struct()
+        graph = csr.struct(rows)
         with _Span('first_hop_mh' if hll_out is None else ('first_hop_hll' if mh_out is None else 'first_hop'), device):
             _native.check(_native.lib().ss_first_hop(byref(graph), _ptr(ab[0]), _ptr(ab[1]), self.num_perm, _ptr(mh_out), self.p,
                                                      _ptr(hll_out), _ptr(cards) if hll_out is not None else None, self.max_hops,

@@ -55,3 +55,74 @@ def test_sharded_query_world2(tmp_path, L):
     mp.spawn(_worker, args=(world, _free_port(), L, str(tmp_path)), nprocs=world, join=True)
     a, b = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
     assert torch.equal(a, b)  # every rank ends with the same, complete, ordered result
+
+
+# ---- sharded build: destination rows partitioned, in-place all-gather after every hop ------------------
+def _build_worker(rank, world, port, n, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import subgraph_sketching_amd as ssa
+    from conftest import oracle_params
+    from oracle import oracle
+    prm = oracle_params(ssa.hll_tables.load(8, prefer='regenerated'))
+    rng = np.random.RandomState(3)
+    e = rng.randint(0, n, size=(2, 3 * n)).astype(np.int64)
+    ei = np.concatenate([e, e[::-1]], axis=1)
+    ei_loops = oracle.add_self_loops(ei)
+    shard = ssa.dist.RowShard(n, None)
+    lo, hi = shard.rows
+    assert shard.padded_rows % world == 0 and shard.padded_rows >= n and 0 <= lo <= hi <= n
+    if world == 2 and n > 2:
+        assert (lo, hi) == ((0, (n + 1) // 2) if rank == 0 else ((n + 1) // 2, n))
+    # the protocol of ElphHashes._build with the oracle standing in for the row-range kernels: each rank fills ONLY the
+    # rows it owns (everything else poisoned), gathers, and must then hold the complete hop to compute the next one
+    mh = torch.from_numpy(oracle.minhash_init(n, 128).view(np.int32))  # packed uint32 carried as int32, like the engine
+    hll = torch.from_numpy(oracle.hll_init(n, 8))
+    cards = torch.full((shard.padded_rows, 2), float('nan'))
+    for k in (1, 2):
+        full_mh, full_hll = oracle.propagate(n, ei_loops, mh=mh.numpy().view(np.uint32), hll=hll.numpy())
+        full_mh = full_mh.view(np.int32)
+        mine_mh = torch.full((shard.padded_rows, 128), -7, dtype=torch.int32)
+        mine_hll = torch.full((shard.padded_rows, 256), 77, dtype=torch.uint8)
+        mine_mh[lo:hi] = torch.from_numpy(full_mh)[lo:hi]
+        mine_hll[lo:hi] = torch.from_numpy(full_hll)[lo:hi]
+        cards[lo:hi, k - 1] = torch.from_numpy(oracle.hll_count(full_hll, prm))[lo:hi]
+        shard.wait(shard.gather(mine_mh))
+        shard.wait(shard.gather(mine_hll))
+        mh, hll = mine_mh[:n].clone(), mine_hll[:n].clone()
+        assert torch.equal(mh, torch.from_numpy(full_mh)), f'rank {rank} hop {k}: MinHash rows differ after the gather'
+        assert torch.equal(hll, torch.from_numpy(full_hll)), f'rank {rank} hop {k}: HLL rows differ after the gather'
+    shard.wait(shard.gather(cards))
+    ref_tables, ref_cards = oracle.build_hash_tables(n, ei, 2, 128, prm)
+    assert np.array_equal(mh.numpy().view(np.uint32), ref_tables[2]['minhash'])
+    assert np.array_equal(hll.numpy(), ref_tables[2]['hll'])
+    assert np.array_equal(cards[:n].numpy(), ref_cards)
+    torch.save((mh, hll, cards[:n]), os.path.join(out_dir, f'build_rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n', [501, 64, 1])
+def test_sharded_build_protocol_world2(tmp_path, n):
+    world = 2
+    mp.spawn(_build_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    a, b = torch.load(tmp_path / 'build_rank0.pt'), torch.load(tmp_path / 'build_rank1.pt')
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_row_shard_bounds():
+    """ownership arithmetic without a process group (RowShard reads world / rank from one)"""
+    import subgraph_sketching_amd as ssa
+    for n in (0, 1, 7, 8, 9, 235868):
+        for world in (1, 2, 3, 8):
+            per = max((n + world - 1) // world, 1)
+            covered = []
+            for rank in range(world):
+                lo = min(rank * per, n)
+                covered.append((lo, min(lo + per, n)))
+            assert covered[0][0] == 0 and covered[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+            assert per * world >= n
+    assert ssa.dist.RowShard.__init__.__code__.co_argcount == 3
