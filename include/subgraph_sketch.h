@@ -159,6 +159,17 @@ int ss_pair_features_normalised(const int64_t *links, int64_t B, int64_t N, int3
                                 const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
                                 const float *degrees, float *out, int32_t *err_flag, void *stream);
 
+/* Weighted common-neighbour scores of node pairs -- the other per-link precompute of HashDataset.__init__ (SURVEY 8(f)
+ * row N4; reference datasets/elph.py:76-77,314 calling heuristics.py:51-70 RA; CN heuristics.py:10-27 and AA :30-48
+ * are the same sum with another multiplier):
+ *     out[q] = (float) sum_w A[u, w] * (A[v, w] * mult[w]),   (u, v) = links[q], fp64 inside like scipy.
+ *   rowptr / col / val: device CSR of A (int64[N+1], int32[nnz] SORTED and duplicate-free inside a row -- what
+ *   scipy.sparse.csr_matrix((w, (row, col))) holds after sum_duplicates/sort_indices --, double[nnz] or NULL = all 1);
+ *   mult: device double[N] or NULL (= 1: common neighbours).  links: device int64[B, 2]; out: device fp32[B].
+ *   err_flag (nullable): set to 1 when a link refers to a node outside [0, N) (its score is written as 0). */
+int ss_common_neighbour_scores(const int64_t *rowptr, const int32_t *col, const double *val, const double *mult,
+                               int64_t N, const int64_t *links, int64_t B, float *out, int32_t *err_flag, void *stream);
+
 /* int64 <-> packed uint32 MinHash tables (the reference's tensors are int64, hashing.py:124). */
 int ss_pack_minhash(const int64_t *in, uint32_t *out, int64_t count, void *stream);
 int ss_unpack_minhash(const uint32_t *in, int64_t *out, int64_t count, void *stream);

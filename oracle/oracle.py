@@ -193,3 +193,25 @@ def append_degree_normalised(x, links, degrees):
     lib().so_append_degree_normalised(_p(x), c_int64(x.shape[0]), c_int32(x.shape[1]), _p(links), c_int64(degrees.shape[0]),
                                       _p(degrees), _p(out))
     return out
+
+
+def common_neighbour_scores(A, links, kind):
+    """heuristics.py:10-70: kind in {'CN', 'AA', 'RA'}; A scipy sparse (any format), links [L, 2] -> float32 [L]"""
+    A = A.tocsr().copy()
+    A.sum_duplicates()
+    rowptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    col = np.ascontiguousarray(A.indices, dtype=np.int32) if A.nnz else np.zeros(1, dtype=np.int32)
+    val = np.ascontiguousarray(A.data, dtype=np.float64) if A.nnz else np.zeros(1, dtype=np.float64)
+    mult = None
+    if kind != 'CN':
+        colsum = np.asarray(A.sum(axis=0)).ravel()
+        with np.errstate(divide='ignore', invalid='ignore'):
+            mult = 1 / (np.log(colsum) if kind == 'AA' else colsum)
+        mult = np.asarray(mult, dtype=np.float64)
+        mult[np.isinf(mult)] = 0
+        mult = np.ascontiguousarray(mult)
+    links = np.ascontiguousarray(np.asarray(links, dtype=np.int64).reshape(-1, 2))
+    out = np.empty(links.shape[0], dtype=np.float32)
+    lib().so_common_neighbour_scores(_p(rowptr), _p(col), _p(val), _p(mult), c_int64(A.shape[0]), _p(links), c_int64(links.shape[0]),
+                                     _p(out))
+    return out

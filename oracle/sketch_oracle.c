@@ -339,3 +339,30 @@ void so_append_degree_normalised(const float *x, int64_t B, int32_t nf, const in
         }
     }
 }
+
+/* heuristics.py:10-70 (CN / AA / RA; RA feeds HashDataset.RA, datasets/elph.py:76-77,314 -- SURVEY.md 8(f) N4):
+ * score[q] = (float) sum_w A[u,w] * (A[v,w] * mult[w]) summed in fp64 in ascending column order, the order scipy's CSR
+ * row sum visits the entries of A[src].multiply(A_[dst]).  CSR rows sorted and duplicate-free; val NULL = all ones,
+ * mult NULL = all ones. */
+void so_common_neighbour_scores(const int64_t *rowptr, const int32_t *col, const double *val, const double *mult, int64_t N,
+                                const int64_t *links, int64_t B, float *out)
+{
+    for (int64_t q = 0; q < B; ++q) {
+        const int64_t u = wrap_index(links[2 * q], N), v = wrap_index(links[2 * q + 1], N);
+        int64_t i = rowptr[u], j = rowptr[v];
+        const int64_t ie = rowptr[u + 1], je = rowptr[v + 1];
+        double acc = 0.0;
+        while (i < ie && j < je) {
+            if (col[i] < col[j]) ++i;
+            else if (col[i] > col[j]) ++j;
+            else {
+                const double a_src = val ? val[i] : 1.0, a_dst = val ? val[j] : 1.0;
+                const double scaled = mult ? a_dst * mult[col[i]] : a_dst;
+                acc += a_src * scaled;
+                ++i;
+                ++j;
+            }
+        }
+        out[q] = (float)acc;
+    }
+}

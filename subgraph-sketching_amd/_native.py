@@ -51,6 +51,8 @@ SIGNATURES = {
     'ss_pair_features_normalised': (c_int32, [c_void_p, c_int64, c_int64, c_int32, POINTER(c_void_p), c_int32,
                                               POINTER(c_void_p), c_void_p, c_int64, POINTER(HllParams), c_uint32, c_void_p,
                                               c_void_p, c_void_p, c_void_p]),
+    'ss_common_neighbour_scores': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                             c_void_p]),
     'ss_pack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_unpack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_profile_enable': (c_int32, [c_int32]),

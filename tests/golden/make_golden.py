@@ -137,6 +137,53 @@ def load_reference_buddy():
     return ref_models.BUDDY
 
 
+def load_reference_heuristics():
+    """the reference's src/heuristics.py (CN / AA / RA); needs only the DataLoader shim, scipy and tqdm"""
+    install_shims()
+    if '/root/reference' not in sys.path:
+        sys.path.insert(0, '/root/reference')
+    import src.heuristics as ref_heuristics
+    return ref_heuristics
+
+
+def make_g10():
+    """G10: CN / AA / RA of the reference on a small weighted directed multigraph (duplicates are summed by csr_matrix,
+    datasets/elph.py:68-71), with isolated nodes, a hub, zero column sums and column sums of 1 (log -> 0 -> inf -> 0)"""
+    import scipy.sparse as ssp
+    H = load_reference_heuristics()
+    rng = np.random.RandomState(5)
+    n = 90
+    src = np.concatenate([rng.randint(0, 80, size=700), np.full(60, 7), rng.randint(0, 80, size=60), [81, 82]])
+    dst = np.concatenate([rng.randint(0, 80, size=700), rng.randint(0, 80, size=60), np.full(60, 7), [83, 83]])
+    w = rng.randint(1, 4, size=src.size).astype(np.int64)
+    A = ssp.csr_matrix((w, (src, dst)), shape=(n, n))       # int64 weights, as the reference builds it
+    links = np.concatenate([rng.randint(0, n, size=(300, 2)), [[7, 7], [7, 3], [3, 7], [85, 86], [81, 82], [82, 81], [0, 0]]]).astype(np.int64)
+    g = {'src': src, 'dst': dst, 'w': w, 'num_nodes': np.asarray(n), 'links': links}
+    lk = torch.from_numpy(links)
+    # the reference indexes scipy matrices with torch tensors (A[src], heuristics.py:21); scipy >= 1.13 rejects those while
+    # probing `idx.dtype.kind`.  Environment shim: hand scipy the same indices as numpy arrays.
+    import scipy.sparse._index as _spi
+    _orig_validate = _spi.IndexMixin._validate_indices
+
+    def _validate_with_tensors(self, key, *a, **kw):
+        conv = (lambda k: k.numpy() if isinstance(k, torch.Tensor) else k)
+        key = tuple(conv(k) for k in key) if isinstance(key, tuple) else conv(key)
+        return _orig_validate(self, key, *a, **kw)
+    _spi.IndexMixin._validate_indices = _validate_with_tensors
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for name in ('CN', 'AA', 'RA'):
+            g[name] = getattr(H, name)(A, lk, batch_size=128)[0].numpy()
+        Af = ssp.csr_matrix((w.astype(np.float64) * 0.37, (src, dst)), shape=(n, n))   # float edge weights
+        g['RA_float_weights'] = H.RA(Af, lk, batch_size=1000)[0].numpy()
+        Au = ssp.csr_matrix((np.ones(src.size, dtype=int), (src, dst)), shape=(n, n))  # edge_weight = ones (datasets/elph.py:62)
+        g['RA_unit_weights'] = H.RA(Au, lk, batch_size=1000)[0].numpy()
+    assert g['RA'].dtype == np.float32 and np.isfinite(g['RA']).all() and (g['CN'] > 0).sum() > 100
+    np.savez_compressed(os.path.join(HERE, 'g10_heuristics.npz'), **g)
+    print('G10 written')
+
+
 def args(h=2, p=8, P=128, floor_sf=False, use_zero_one=True):
     return Namespace(max_hash_hops=h, hll_p=p, minhash_num_perm=P, floor_sf=floor_sf, use_zero_one=use_zero_one)
 
@@ -357,4 +404,8 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if '--only-g10' in sys.argv:
+        make_g10()
+    else:
+        main()
+        make_g10()

@@ -206,3 +206,24 @@ def test_degree_normalised_features_vs_reference(h):
     assert np.array_equal(got, g[f'normed_h{h}']), 'sqrt / divide / NaN-Inf rule must be bit-exact'
     zero_rows = (g['degrees'][g['links'][:, 0]] == 0) | (g['degrees'][g['links'][:, 1]] == 0)
     assert zero_rows.any() and not got[zero_rows][:, base.shape[1]:].any()
+
+
+def _g10_matrices():
+    import scipy.sparse as ssp
+    g = load_golden('g10_heuristics.npz')
+    n = int(g['num_nodes'])
+    coo = (g['src'], g['dst'])
+    return g, {'': ssp.csr_matrix((g['w'], coo), shape=(n, n)),
+               '_float_weights': ssp.csr_matrix((g['w'].astype(np.float64) * 0.37, coo), shape=(n, n)),
+               '_unit_weights': ssp.csr_matrix((np.ones(g['src'].size, dtype=int), coo), shape=(n, n))}
+
+
+def test_common_neighbour_heuristics_vs_reference():
+    """CN / AA / RA of the reference's src/heuristics.py (G10): the oracle sums in fp64 in column order like scipy, so the
+    float32 results are bit-identical"""
+    g, mats = _g10_matrices()
+    for kind in ('CN', 'AA', 'RA'):
+        got = oracle.common_neighbour_scores(mats[''], g['links'], kind)
+        assert got.dtype == np.float32 and np.array_equal(got, g[kind]), kind
+    for suffix in ('_float_weights', '_unit_weights'):
+        assert np.array_equal(oracle.common_neighbour_scores(mats[suffix], g['links'], 'RA'), g['RA' + suffix]), suffix
