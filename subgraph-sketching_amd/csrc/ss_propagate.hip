@@ -111,7 +111,24 @@ __global__ __launch_bounds__(256) void hll_propagate_row16_kernel(GraphArgs g, c
     const bool want_cards = cards_out != nullptr;
     EstimatorTables est;
     if (want_cards) est = stage_tables(lds, prm);
-    const int64_t row = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kRow) + threadIdx.x / kRow;
+    // the 16 rows of this workgroup are dealt to its 16 lane groups in DEGREE order: the four rows that share a wavefront
+    // then have similar degrees, and the walk of a wavefront lasts as long as its longest row
+    __shared__ int s_deg[256 / kRow], s_owner[256 / kRow];
+    const int grp = threadIdx.x / kRow, c16 = threadIdx.x & (kRow - 1);
+    const int64_t first = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kRow);
+    {
+        const int64_t r = first + grp;
+        const int d = r < g.row1 ? (int)(g.rowptr[r + 1] - g.rowptr[r]) : -1;
+        if (c16 == 0) s_deg[grp] = d;
+        __syncthreads();
+        const int dj = s_deg[c16];
+        const bool before = dj < d || (dj == d && c16 < grp);
+        const unsigned long long b = __ballot(before);
+        const int rank = __popcll((b >> (kRow * ((threadIdx.x & (kWave - 1)) / kRow))) & 0xFFFFull);
+        if (c16 == 0) s_owner[rank] = grp;
+        __syncthreads();
+    }
+    const int64_t row = first + s_owner[grp];
     hll_hop_row16(g, row < g.row1 ? row : -1, skip_hubs, hll_in, hll_out, cards_out, cards_stride, est, want_cards, threadIdx.x & (kRow - 1));
 }
 
