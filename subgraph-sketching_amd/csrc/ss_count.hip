@@ -4,6 +4,8 @@
 
 namespace ss {
 
+constexpr int kCountRows = 4;  // rows per lane group and workgroup pass: 4 independent 16-byte loads in flight per lane
+
 __global__ __launch_bounds__(256) void hll_count_kernel(const uint8_t *__restrict__ regs, int64_t n, int M,
                                                         float *__restrict__ out, int64_t out_stride, ss_hll_params prm)
 {
@@ -15,23 +17,52 @@ __global__ __launch_bounds__(256) void hll_count_kernel(const uint8_t *__restric
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / SG, cl = lane % SG;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-    const int64_t row = wave * G + g;
-    int nonzero = 0;
-    float hsum = 0.0f;
-    if (row < n) {
-        for (int c = cl; c < CH; c += SG) {
-            const u32x4 x = *reinterpret_cast<const u32x4 *>(regs + row * M + 16 * c);
-            hll_dword_stats(x.x, nonzero, hsum);
-            hll_dword_stats(x.y, nonzero, hsum);
-            hll_dword_stats(x.z, nonzero, hsum);
-            hll_dword_stats(x.w, nonzero, hsum);
+    const int64_t row0 = (wave * G + g) * kCountRows;
+    int nonzero[kCountRows];
+    float hsum[kCountRows];
+#pragma unroll
+    for (int r = 0; r < kCountRows; ++r) {
+        nonzero[r] = 0;
+        hsum[r] = 0.0f;
+    }
+    for (int c = cl; c < CH; c += SG) {
+        u32x4 x[kCountRows];
+#pragma unroll
+        for (int r = 0; r < kCountRows; ++r)
+            x[r] = row0 + r < n ? *reinterpret_cast<const u32x4 *>(regs + (row0 + r) * M + 16 * c) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < kCountRows; ++r) {
+            hll_dword_stats(x[r].x, nonzero[r], hsum[r]);
+            hll_dword_stats(x[r].y, nonzero[r], hsum[r]);
+            hll_dword_stats(x[r].z, nonzero[r], hsum[r]);
+            hll_dword_stats(x[r].w, nonzero[r], hsum[r]);
         }
     }
-    for (int off = 1; off < SG; off <<= 1) {
-        nonzero += __shfl_xor(nonzero, off);
-        hsum += __shfl_xor(hsum, off);
+#pragma unroll
+    for (int r = 0; r < kCountRows; ++r) {
+        for (int off = 1; off < SG; off <<= 1) {
+            nonzero[r] += __shfl_xor(nonzero[r], off);
+            hsum[r] += __shfl_xor(hsum[r], off);
+        }
+        // lane r of the group finishes row r (the estimator is a few dozen dependent instructions: 4 lanes run it at once)
     }
-    if (row < n && cl == 0) out[row * out_stride] = hll_estimate(est, M - nonzero, hsum);
+    int my_nz = nonzero[0];
+    float my_hs = hsum[0];
+#pragma unroll
+    for (int r = 1; r < kCountRows; ++r) {
+        my_nz = (cl == r) ? nonzero[r] : my_nz;
+        my_hs = (cl == r) ? hsum[r] : my_hs;
+    }
+    const int my_r = SG >= kCountRows ? cl : 0;
+    if (SG >= kCountRows) {
+        if (cl < kCountRows && row0 + my_r < n) out[(row0 + my_r) * out_stride] = hll_estimate(est, M - my_nz, my_hs);
+    } else {  // M == 16 or 32: fewer lanes than rows per group
+        if (cl == 0) {
+#pragma unroll
+            for (int r = 0; r < kCountRows; ++r)
+                if (row0 + r < n) out[(row0 + r) * out_stride] = hll_estimate(est, M - nonzero[r], hsum[r]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void estimate_bias_kernel(const float *__restrict__ e, int64_t n, float *__restrict__ out,
@@ -75,7 +106,7 @@ extern "C" int ss_hll_count(const uint8_t *regs, int64_t n, const ss_hll_params 
     const int M = 1 << prm->p;
     const int CH = M >> 4;
     const int SG = CH > kWave ? kWave : CH;
-    const int rows_per_block = (256 / kWave) * (kWave / SG);
+    const int rows_per_block = (256 / kWave) * (kWave / SG) * kCountRows;
     const int64_t blocks = (n + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(hll_count_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, regs, n, M, out, out_stride,
                        *prm);

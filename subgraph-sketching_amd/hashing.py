@@ -260,6 +260,66 @@ def unpack_minhash(x_u32):
     return out
 
 
+LAZY_MINHASH = True  # minhash_prop returns its int64 result as a LazyMinhash (materialised on first outside use)
+
+
+class LazyMinhash(torch.Tensor):
+    """The int64 [N, P] tensor `minhash_prop` owes its caller (reference hashing.py:28-35 returns int64), backed by the
+    packed uint32 table the kernel actually wrote.  ELPH.forward (reference models/elph.py:209-212) only ever hands the
+    tensor back to this engine (next hop, get_subgraph_features), which reads the packed table directly; the 8-byte
+    copy -- 241 MB per hop at ogbl-collab size, 70 us -- is made the first time anything ELSE touches the tensor: every
+    torch operator (indexing, comparison, .cpu(), printing, torch.save ...) sees an ordinary int64 tensor from then on.
+    From that moment the materialised tensor is the truth and the packed table is dropped: views handed out from inside
+    __torch_dispatch__ do not share a version counter with their base, so edits through them cannot be detected -- the
+    engine therefore re-packs a materialised LazyMinhash every time it is given one (the rare path)."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @staticmethod
+    def __new__(cls, packed):
+        return torch.Tensor._make_wrapper_subclass(cls, packed.shape, dtype=torch.int64, device=packed.device, requires_grad=False)
+
+    def __init__(self, packed):
+        self._packed, self._real = packed, None
+
+    def materialise(self):
+        if self._real is None:
+            self._real = unpack_minhash(self._packed)
+            self._packed = None
+        return self._real
+
+    def packed_if_valid(self):
+        """the packed table while nothing outside the engine has seen (and possibly edited) the int64 form"""
+        return self._packed if self._real is None else None
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+
+        def real(x):
+            return x.materialise() if isinstance(x, LazyMinhash) else x
+        return func(*tree_map(real, args), **tree_map(real, kwargs or {}))
+
+    # entry points that bypass the dispatcher
+    def numpy(self, *args, **kwargs):
+        return self.materialise().numpy(*args, **kwargs)
+
+    def tolist(self):
+        return self.materialise().tolist()
+
+    def data_ptr(self):
+        return self.materialise().data_ptr()
+
+    def __array__(self, *args, **kwargs):
+        return self.materialise().__array__(*args, **kwargs)
+
+    def __reduce_ex__(self, proto):
+        return self.materialise().__reduce_ex__(proto)
+
+    def __deepcopy__(self, memo):
+        return self.materialise().clone()
+
+
 def _tag(t, name, twin):
     """attach a packed twin to a reference-shaped tensor, stamped with the tensor's version counter so that any
     in-place edit invalidates it"""
@@ -271,6 +331,11 @@ def _tag(t, name, twin):
 
 def _packed_minhash_of(t, device):
     """packed twin of a reference-shaped int64 MinHash tensor (cached on the tensor object)"""
+    if isinstance(t, LazyMinhash):
+        tw = t.packed_if_valid()
+        if tw is not None and tw.device == device:
+            return tw
+        return pack_minhash(t.materialise(), device)  # never cached: see the class docstring
     tag = getattr(t, '_ss_u32', None)
     if tag is not None and tag[0] == t._version and tag[1].device == device and tag[1].shape == t.shape:
         return tag[1]  # still valid: the tensor has not been edited in place since the twin was made
@@ -400,13 +465,14 @@ def _hop0_marker(x, device):
     return tag[1], tag[2]
 
 
-def _first_hop_from_ids(csr, device, perms, num_perm, p, mh_out, hll_out):
+def _first_hop_from_ids(csr, device, perms, num_perm, p, mh_out, hll_out, cards_out=None, params=None):
     """ss_first_hop for one sketch; returns False when the fused kernel has no variant for (num_perm, p)"""
     graph = csr.struct()
     with _Span('first_hop', device):
         rc = _native.lib().ss_first_hop(byref(graph), _ptr(perms[0]) if perms is not None else None,
                                         _ptr(perms[1]) if perms is not None else None, num_perm, _ptr(mh_out), p,
-                                        _ptr(hll_out), None, 0, None, _stream(device))
+                                        _ptr(hll_out), _ptr(cards_out), 1 if cards_out is not None else 0,
+                                        byref(params.struct) if cards_out is not None else None, _stream(device))
     if rc == -4:
         return False
     _native.check(rc, 'ss_first_hop')
@@ -433,6 +499,8 @@ class MinhashPropagation(object):
                 out_u32 = None
         if out_u32 is None:
             out_u32, _ = _propagate(csr, _packed_minhash_of(x, device), None, device)
+        if LAZY_MINHASH and x.device == device:
+            return LazyMinhash(out_u32)
         out = unpack_minhash(out_u32)
         _tag(out, '_ss_u32', out_u32)
         return out if x.device == device else out.to(x.device)
@@ -443,8 +511,12 @@ class MinhashPropagation(object):
 class HllPropagation(object):
     """drop-in for reference hashing.py:38-45: out[i] = element-wise max over in-neighbours of x[j]"""
 
-    def __init__(self, csr_cache=None):
+    def __init__(self, csr_cache=None, params_of=None, m=None):
+        """params_of(device) -> _DeviceParams and m: given by the ElphHashes that owns this module; the kernels then also
+        produce the HLL++ cardinality of every output row (free: the registers are in flight) and ElphHashes.hll_count of
+        that very tensor (reference models/elph.py:213) is answered without another pass over the table"""
         self._cache = csr_cache or _default_csr_cache
+        self._params_of, self._m = params_of, m
 
     @torch.no_grad()
     def forward(self, x, edge_index):
@@ -455,16 +527,20 @@ class HllPropagation(object):
         csr = self._cache.get(edge_index, x.size(0), device)
         hop0 = _hop0_marker(x, device)
         out_u8 = None
+        params = self._params_of(device) if (self._params_of is not None and M == self._m) else None
+        counts = torch.empty(x.size(0), dtype=torch.float32, device=device) if params is not None else None
         if hop0 is not None and hop0[0] is None and M == 256:
             out_u8 = torch.empty((x.size(0), M), dtype=torch.uint8, device=device)
-            if not _first_hop_from_ids(csr, device, None, 128, hop0[1], None, out_u8):
+            if not _first_hop_from_ids(csr, device, None, 128, hop0[1], None, out_u8, counts, params):
                 out_u8 = None
         if out_u8 is None:
-            _, out_u8 = _propagate(csr, None, _packed_hll_of(x, device), device)
+            _, out_u8 = _propagate(csr, None, _packed_hll_of(x, device), device, cards_out=counts, cards_stride=1, params=params)
         out = out_u8.view(torch.int8) if x.dtype != torch.uint8 else out_u8
         if out.dtype != x.dtype:
             out = out.to(x.dtype)
         _tag(out, '_ss_u8', out_u8)
+        if counts is not None:
+            _tag(out, '_ss_count', counts)
         return out if x.device == device else out.to(x.device)
 
     __call__ = forward
@@ -502,7 +578,7 @@ class ElphHashes(object):
         self.hll_threshold = self.hll_tables.threshold
         self.bias_vector = torch.tensor(self.hll_tables.bias, dtype=torch.float)
         self.estimate_vector = torch.tensor(self.hll_tables.raw_estimate, dtype=torch.float)
-        self.hll_prop = HllPropagation(self._csr_cache)
+        self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m)
         self._dev_params = {}
         self._dev_perms = {}
         self.fuse_first_hop = True  # compute hop 1 straight from node ids when the fused kernel supports (num_perm, p)
@@ -520,7 +596,7 @@ class ElphHashes(object):
         self.__dict__.update(state)
         self._csr_cache = _CsrCache()
         self.minhash_prop = MinhashPropagation(self._csr_cache)
-        self.hll_prop = HllPropagation(self._csr_cache)
+        self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m)
 
     # ---- host-side helpers -------------------------------------------------------------------------
     def _params(self, device):
@@ -799,6 +875,11 @@ class ElphHashes(object):
         if regs.size(1) != self.m:
             raise ValueError(f'expected rows of {self.m} registers, got {regs.size(1)}')
         device = _compute_device(regs)
+        tag = getattr(regs, '_ss_count', None)
+        if tag is not None:  # produced together with `regs` by hll_prop (same kernel arithmetic); handed out once
+            regs._ss_count = None
+            if tag[0] == regs._version and tag[1].device == device and tag[1].numel() == regs.size(0):
+                return tag[1] if regs.device == device else tag[1].to(regs.device)
         params = self._params(device)
         packed = _packed_hll_of(regs, device)
         out = torch.empty(regs.size(0), dtype=torch.float32, device=device)
