@@ -12,7 +12,8 @@ step     : one pass of the whole hot path over one batch: ElphHashes.build_hash_
            per edge set.  Nothing is cached between steps.  Inputs (edge_index, links) are resident in HBM.
 N > 1    : one process per GPU (torchrun), sketch table replicated (every rank builds it), edge batches
            sharded -- each rank owns its own B pairs -- and the per-batch feature rows all-gathered over
-           RCCL (all_gather_into_tensor, inside the timed region).  Weak scaling.
+           RCCL (async all_gather_into_tensor on RCCL's stream, overlapped with the next step's build, double-buffered,
+           every gather completed inside the timed region).  Weak scaling.
 roofline : dominant kernel = ss::propagate_kernel (one launch per hop).  achieved = algorithmic bytes per
            launch ((E'+N)*768 + 4E' + 8(N+1) + 4N, E' = E_dir + N) / mean launch
            duration measured live in the timed region with HIP events on the launch stream.
@@ -183,7 +184,23 @@ def main():
     links_np = synthetic_links(2 + rank)
     ei = torch.from_numpy(ei_np).to(dev)
     links = torch.from_numpy(links_np).to(dev)
-    gathered = torch.empty((world * BATCH, H * (H + 2)), dtype=torch.float32, device=dev) if launched else None
+    # the per-batch feature gather runs on RCCL's stream UNDER the next step's build (double-buffered); every gather is
+    # completed inside the timed region (drain() before the closing fence)
+    gathered = [torch.empty((world * BATCH, H * (H + 2)), dtype=torch.float32, device=dev) for _ in range(2)] if launched else None
+    inflight = {'work': None, 'src': None, 'n': 0}
+
+    def gather(f):
+        if not launched:
+            return
+        drain()  # the previous gather (issued one step ago) has long finished; frees its buffer for the one after next
+        inflight['work'] = dist.all_gather_into_tensor(gathered[inflight['n'] % 2], f, async_op=True)
+        inflight['src'] = f
+        inflight['n'] += 1
+
+    def drain():
+        if inflight['work'] is not None:
+            inflight['work'].wait()
+            inflight['work'], inflight['src'] = None, None
 
     sharded_build = launched and world > 1 and a.build == 'sharded'
 
@@ -195,8 +212,7 @@ def main():
     def step_build_query():
         table, cards = build_tables()
         f = eh.get_subgraph_features(links, table, cards)
-        if launched:
-            dist.all_gather_into_tensor(gathered, f)
+        gather(f)
         return f
 
     elph_state = {}
@@ -214,8 +230,7 @@ def main():
                         'minhash': eh.minhash_prop(table[k - 1]['minhash'], hash_edge_index)}
             cards[:, k - 1] = eh.hll_count(table[k]['hll'])
         f = eh.get_subgraph_features(links, table, cards)
-        if launched:
-            dist.all_gather_into_tensor(gathered, f)
+        gather(f)
         return f
 
     def step_buddy():
@@ -223,14 +238,14 @@ def main():
         table, cards = build_tables()
         for _ in range(a.buddy_batches):
             f = eh.get_subgraph_features(links, table, cards)
-            if launched:
-                dist.all_gather_into_tensor(gathered, f)
+            gather(f)
         return f
 
     step = {'build_query': step_build_query, 'elph': step_elph, 'buddy': step_buddy}[a.api]
     pairs_per_step = BATCH * (a.buddy_batches if a.api == 'buddy' else 1)
 
     def fence():
+        drain()
         torch.cuda.synchronize(dev)
         if launched:
             dist.barrier()
