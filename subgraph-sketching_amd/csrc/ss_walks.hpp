@@ -227,7 +227,30 @@ __device__ __forceinline__ void hll_hop_row16(const GraphArgs &g, int64_t row, b
     const bool hub = skip_hubs && deg > g.hub_threshold;
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
     const int total = (!ok || hub) ? 0 : deg + (i < n_self ? 1 : 0);
-    const u32x4 acc = hll_walk(hll_in, g.col + rb, deg, total, i, 0, 1, M, c);
+    // every lane group walks the first kSolo neighbours of its own row; what is left of longer rows is walked by the whole
+    // wavefront, one row at a time (group g takes every 4th neighbour), so a wavefront lasts about sum(excess)/4 instead
+    // of max(degree) iterations -- skewed graphs put rows of 10 and of 500 neighbours into the same wavefront
+    constexpr int kSolo = 32;
+    const int32_t *nb = g.col + rb;
+    u32x4 acc = hll_walk(hll_in, nb, deg, total < kSolo ? total : kSolo, i, 0, 1, M, c);
+    const unsigned long long long_rows = __ballot(total > kSolo);
+    if (long_rows) {
+        const int grp = (threadIdx.x & (kWave - 1)) / kRow;
+#pragma unroll
+        for (int gg = 0; gg < kWave / kRow; ++gg) {
+            if (!((long_rows >> (kRow * gg)) & 1ull)) continue;  // wave-uniform
+            const uint64_t nb_bits = (uint64_t)(uintptr_t)nb;
+            const int32_t *nb_g = (const int32_t *)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(nb_bits >> 32), kRow * gg) << 32) |
+                                                             (uint32_t)__builtin_amdgcn_readlane((int)nb_bits, kRow * gg));
+            const int deg_g = __builtin_amdgcn_readlane(deg, kRow * gg), total_g = __builtin_amdgcn_readlane(total, kRow * gg);
+            const int64_t i_g = ((int64_t)__builtin_amdgcn_readlane((int)((uint64_t)i >> 32), kRow * gg) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)i, kRow * gg);
+            u32x4 part = hll_walk(hll_in, nb_g, deg_g, total_g, i_g, kSolo + grp, kWave / kRow, M, c);
+            part = bytemax16(part, shfl_xor4(part, 16));
+            part = bytemax16(part, shfl_xor4(part, 32));
+            if (grp == gg) acc = bytemax16(acc, part);
+        }
+    }
     int nonzero = 0;
     float hsum = 0.0f;
     if (want_cards) {

@@ -12,6 +12,7 @@ tensors), HyperLogLog uint8[N, M].  `build_hash_tables` returns a `SketchTable`,
 leaves are only materialised if somebody reads them (torch.save does); the kernels use the packed twin.
 """
 import logging
+import os
 import weakref
 from collections import OrderedDict
 from collections.abc import Mapping
@@ -362,7 +363,16 @@ def _packed_hll_of(t, device):
 # ------------------------------------------------------------------------------------------------
 # CSR cache
 # ------------------------------------------------------------------------------------------------
-HUB_THRESHOLD = 512  # rows with more in-edges than this are propagated by a 16-wave workgroup instead of one wavefront
+# Rows with more in-edges than the hub threshold are propagated by a 16-wave workgroup instead of one wavefront (MinHash) /
+# one 16-lane group (HLL).  None = adaptive: a single wavefront walking d neighbour rows takes ~0.35 us * d, which must
+# stay well below the whole hop (~E * 40 ps): d <= E / 16384, clamped to [128, 1024].  Measured (power-law endpoints,
+# alpha 0.5): collab size 0.754 -> 0.674 ms per step with 144 instead of 512; ppa size flat between 512 and 2048 and 11 %
+# slower at 128 (too many rows on the cooperative path).  SS_HUB_THRESHOLD / this constant force a value.
+HUB_THRESHOLD = int(os.environ['SS_HUB_THRESHOLD']) if 'SS_HUB_THRESHOLD' in os.environ else None
+
+
+def default_hub_threshold(num_edges):
+    return int(min(max(num_edges // 16384, 128), 1024))
 
 
 class CsrGraph(object):
@@ -397,7 +407,8 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
         raise ValueError('edge_index must have shape [2, num_edges]')
     src, dst = ei[0].contiguous(), ei[1].contiguous()
     E = src.numel()
-    hub_threshold = HUB_THRESHOLD if hub_threshold is None else hub_threshold
+    if hub_threshold is None:
+        hub_threshold = HUB_THRESHOLD if HUB_THRESHOLD is not None else default_hub_threshold(E)
     rowptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=device)
     col = torch.empty(max(E, 1), dtype=torch.int32, device=device)
     flags = torch.empty(2, dtype=torch.int64, device=device)  # [0] = n_self, [1] = hub count (both cleared by the kernels)
