@@ -100,6 +100,8 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
 // HLL-only first hop, latency-optimised: one 16-lane DPP row per destination (4 destinations in flight per wave).
 // Used when the caller asks for the HLL sketch alone (the two-stream build runs the HLL chain beside the MinHash
 // chain); the one-row-per-wave kernel above is a single dependent chain per wave and takes 4x longer for this.
+constexpr int kHllRows = 4;
+
 __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, uint8_t *__restrict__ hll_out,
                                                             float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm,
                                                             bool skip_hubs)
@@ -111,45 +113,63 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
     if (want_cards) est = stage_tables(lds, prm);
     const int l = threadIdx.x & (kRow - 1);
     const int grp = threadIdx.x / kRow;
-    const int64_t i_raw = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kRow) + grp;
-    const bool ok = i_raw < g.row1;
-    const int64_t i = ok ? i_raw : g.row1 - 1;
-    uint32_t *row = rows[grp];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4 *>(row + 64 * k + 4 * l) = u32x4{0u, 0u, 0u, 0u};
-    const int64_t rb = g.rowptr[i];
-    const int deg = (int)(g.rowptr[i + 1] - rb);
-    const bool hub = skip_hubs && deg > g.hub_threshold;
+    // kHllRows rows per lane group, one after the other through the same LDS row image; the row bounds and the first
+    // neighbour ids of ALL of them are requested up front, so the two dependent global round trips (rowptr -> col) of
+    // the later rows hide under the work of the earlier ones
+    const int64_t first = g.row0 + ((int64_t)blockIdx.x * (blockDim.x / kRow) + grp) * kHllRows;
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
-    const int total = hub ? 0 : deg + (i < n_self ? 1 : 0);
-    const int32_t *nb = g.col + rb;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int t = l; t < total; t += kRow) {
-        const int64_t nid = t < deg ? (int64_t)nb[t] : i;
-        const uint64_t hv = hash_u64((uint64_t)(nid + 1));
-        const uint64_t bits = hv >> p;
-        const int bl = bits ? 64 - __builtin_clzll(bits) : 0;
-        atomicMax(&row[(uint32_t)hv & 255u], (uint32_t)((64 - p) - bl + 1));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // lane l owns registers 16l .. 16l+15
-    u32x4 packed;
-    uint32_t *pw = reinterpret_cast<uint32_t *>(&packed);
+    uint32_t *row = rows[grp];
+    int64_t rbs[kHllRows];
+    int degs[kHllRows], nid0[kHllRows];
+    bool oks[kHllRows];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pw[k] = pack_hll_quad(row + 16 * l, k);
-    int nonzero = 0;
-    float hsum = 0.0f;
-    if (want_cards) {
-        hll_dword_stats(packed.x, nonzero, hsum);
-        hll_dword_stats(packed.y, nonzero, hsum);
-        hll_dword_stats(packed.z, nonzero, hsum);
-        hll_dword_stats(packed.w, nonzero, hsum);
-        nonzero = row16_sum_i(nonzero);
-        hsum = row16_sum_f(hsum);
+    for (int r = 0; r < kHllRows; ++r) {
+        oks[r] = first + r < g.row1;
+        const int64_t i = oks[r] ? first + r : g.row1 - 1;
+        rbs[r] = g.rowptr[i];
+        degs[r] = (int)(g.rowptr[i + 1] - rbs[r]);
     }
-    if (ok && !hub) {
-        *reinterpret_cast<u32x4 *>(hll_out + i * 256 + 16 * l) = packed;
-        if (want_cards && l == 0) cards_out[i * cards_stride] = hll_estimate(est, 256 - nonzero, hsum);
+#pragma unroll
+    for (int r = 0; r < kHllRows; ++r) nid0[r] = l < degs[r] ? g.col[rbs[r] + l] : -1;
+#pragma unroll
+    for (int r = 0; r < kHllRows; ++r) {
+        const bool ok = oks[r];
+        const int64_t i = ok ? first + r : g.row1 - 1;
+        const int deg = degs[r];
+        const bool hub = skip_hubs && deg > g.hub_threshold;
+        const int total = hub ? 0 : deg + (i < n_self ? 1 : 0);
+        const int32_t *nb = g.col + rbs[r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4 *>(row + 64 * k + 4 * l) = u32x4{0u, 0u, 0u, 0u};
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int t = l; t < total; t += kRow) {
+            const int64_t nid = t < deg ? (t < kRow ? (int64_t)nid0[r] : (int64_t)nb[t]) : i;
+            const uint64_t hv = hash_u64((uint64_t)(nid + 1));
+            const uint64_t bits = hv >> p;
+            const int bl = bits ? 64 - __builtin_clzll(bits) : 0;
+            atomicMax(&row[(uint32_t)hv & 255u], (uint32_t)((64 - p) - bl + 1));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // lane l owns registers 16l .. 16l+15
+        u32x4 packed;
+        uint32_t *pw = reinterpret_cast<uint32_t *>(&packed);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pw[k] = pack_hll_quad(row + 16 * l, k);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        int nonzero = 0;
+        float hsum = 0.0f;
+        if (want_cards) {
+            hll_dword_stats(packed.x, nonzero, hsum);
+            hll_dword_stats(packed.y, nonzero, hsum);
+            hll_dword_stats(packed.z, nonzero, hsum);
+            hll_dword_stats(packed.w, nonzero, hsum);
+            nonzero = row16_sum_i(nonzero);
+            hsum = row16_sum_f(hsum);
+        }
+        if (ok && !hub) {
+            *reinterpret_cast<u32x4 *>(hll_out + i * 256 + 16 * l) = packed;
+            if (want_cards && l == 0) cards_out[i * cards_stride] = hll_estimate(est, 256 - nonzero, hsum);
+        }
     }
 }
 
@@ -252,7 +272,7 @@ int launch_first_hop(const GraphArgs &g, const uint64_t *a, const uint64_t *b, u
         // both sketches: the latency-optimised HLL kernel + the MinHash kernel beat the combined kernel (37 + 134 us vs
         // 184 us on the bench graph); one hub pass serves both
         const bool hubs = g.hub_rows && g.hub_count;
-        hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 15) / 16)), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
+        hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows))), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
                            prm, hubs);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL((first_hop_kernel<PPL, true, false>), dim3((unsigned)((g.rows() + 3) / 4)), dim3(256), 0, s, g, a, b, mh_out, p,
@@ -263,7 +283,7 @@ int launch_first_hop(const GraphArgs &g, const uint64_t *a, const uint64_t *b, u
     if (mh_out) return launch_first_hop_v<PPL, true, false>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
     // HLL alone: 16-lane-per-row kernel for the regular rows, the cooperative hub kernel for the rest
     const bool hubs = g.hub_rows && g.hub_count;
-    hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 15) / 16)), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
+    hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows))), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
                        prm, hubs);
     SS_LAUNCH_CHECK();
     if (hubs) {
