@@ -15,10 +15,14 @@
 //   pass 1  count_keys -> scan_block_counts -> scan_bases -> scatter_tiles    edges -> <= 256 buckets by dst >> shift1
 //   pass 2  (only when there are more than 256 fine buckets) the same three steps inside every pass-1 bucket,
 //           a fixed number of workgroups per bucket, <= 256 sub-buckets each
+//   pass 3  (only when there are more than 65 536 fine buckets: N > 67 M nodes, or > 4 M nodes of a dense graph) once more
+//           inside every pass-2 bucket
 //   finish  one workgroup per fine bucket: LDS histogram over its nodes, LDS scan -> rowptr, sources placed into an
 //           LDS image of the bucket's col segment and streamed out (oversized buckets: several node sub-ranges)
 // The pass-1 scatter also validates ids and reduces max(id)+1 (the self-loop count of add_self_loops,
 // hashing.py:148); the finish step lists hub rows.  Nothing synchronises with the host.
+#include <cstdlib>
+
 #include "ss_common.hpp"
 
 namespace ss {
@@ -40,6 +44,10 @@ struct CsrPlan {
     int blocks1;
     int64_t slice1;
     int parts2;           // workgroups per pass-1 bucket in pass 2
+    bool three_pass;      // more than 65 536 fine buckets: pass 2 stops at shift2, pass 3 (256 keys) reaches node_shift
+    int shift2;           // pass-2 key = dst >> shift2 (three_pass only; otherwise pass 2 keys on node_shift)
+    int keys3, parts3;
+    int64_t groups3;      // keys1 * keys2 pass-2 buckets, each partitioned by pass 3
 };
 
 inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
@@ -52,9 +60,18 @@ inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
     int shift = 10;
     if (((n + 1023) >> 10) > kMaxKeys)
         while (shift > 6 && (E / n) * ((int64_t)1 << shift) > kFinishCap / 2) --shift;
+    if (const char *forced = getenv("SS_CSR_NODE_SHIFT")) {  // test hook: reach the multi-pass plans with small graphs
+        const int f = atoi(forced);
+        if (f >= 4 && f <= 10) shift = f;
+    }
     p.node_shift = shift;
     p.fine_buckets = (n + ((int64_t)1 << shift) - 1) >> shift;
     p.two_pass = p.fine_buckets > kMaxKeys;
+    p.three_pass = false;
+    p.shift2 = shift;
+    p.keys3 = 1;
+    p.parts3 = 1;
+    p.groups3 = 0;
     if (!p.two_pass) {
         p.shift1 = shift;
         p.keys1 = (int)p.fine_buckets;
@@ -62,10 +79,18 @@ inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
     } else {
         int s1 = shift;
         while (((n + ((int64_t)1 << s1) - 1) >> s1) > kMaxKeys) ++s1;
-        if (s1 - shift > 8) return false;  // would need a third pass (N > 16 M nodes at 64-node buckets)
+        if (s1 - shift > 16) return false;  // would need a fourth pass (N > 2^30 nodes at 64-node buckets)
         p.shift1 = s1;
         p.keys1 = (int)((n + ((int64_t)1 << s1) - 1) >> s1);
-        p.keys2 = 1 << (s1 - shift);
+        if (s1 - shift <= 8) {
+            p.keys2 = 1 << (s1 - shift);
+        } else {  // N > 256 * 256 fine buckets (4 M nodes at 64-node buckets, 67 M at 1024): one more 8-bit partition
+            p.three_pass = true;
+            p.shift2 = shift + 8;
+            p.keys2 = 1 << (s1 - p.shift2);
+            p.keys3 = 256;
+            p.groups3 = (int64_t)p.keys1 * p.keys2;
+        }
     }
     int64_t b1 = (E + kTile - 1) / kTile;
     if (b1 < 1) b1 = 1;
@@ -85,7 +110,9 @@ struct Workspace {
     uint32_t *counts1;              // [keys1][blocks1]
     unsigned long long *base1;      // [keys1 + 1]
     uint32_t *counts2;              // [keys1][keys2][parts2]
-    unsigned long long *fine_base;  // [fine_buckets + 1]
+    unsigned long long *fine_base;  // [fine_buckets + 1] (three_pass: [groups3 + 1], the pass-2 bucket bases)
+    uint32_t *counts3;              // [groups3][keys3][parts3]
+    unsigned long long *fine_base3; // [fine_buckets + 1]
     unsigned long long *scratch;    // [1] n_self when the caller does not want it
     int2 *staged_a, *staged_b;      // [E] each
     size_t bytes;
@@ -100,7 +127,9 @@ inline Workspace carve(const CsrPlan &p, int64_t E, void *base)
     w.counts1 = reinterpret_cast<uint32_t *>(take((size_t)p.keys1 * p.blocks1 * 4));
     w.base1 = reinterpret_cast<unsigned long long *>(take((size_t)(p.keys1 + 1) * 8));
     w.counts2 = reinterpret_cast<uint32_t *>(take(p.two_pass ? (size_t)p.keys1 * p.keys2 * p.parts2 * 4 : 0));
-    w.fine_base = reinterpret_cast<unsigned long long *>(take(p.two_pass ? (size_t)(p.fine_buckets + 1) * 8 : 0));
+    w.fine_base = reinterpret_cast<unsigned long long *>(take(p.two_pass ? (size_t)((p.three_pass ? p.groups3 : p.fine_buckets) + 1) * 8 : 0));
+    w.counts3 = reinterpret_cast<uint32_t *>(take(p.three_pass ? (size_t)p.groups3 * p.keys3 * p.parts3 * 4 : 0));
+    w.fine_base3 = reinterpret_cast<unsigned long long *>(take(p.three_pass ? (size_t)(p.fine_buckets + 1) * 8 : 0));
     w.scratch = reinterpret_cast<unsigned long long *>(take(8));
     w.staged_a = reinterpret_cast<int2 *>(take((size_t)(E > 0 ? E : 1) * 8));
     w.staged_b = reinterpret_cast<int2 *>(take(p.two_pass ? (size_t)(E > 0 ? E : 1) * 8 : 0));
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void scan_sub_counts_kernel(uint32_t *__r
         const int64_t f = (int64_t)c * keys2 + threadIdx.x;
         if (f < fine_buckets) fine_base[f] = base1[c] + ex;
     }
-    if (c == keys1 - 1 && threadIdx.x == 0) fine_base[fine_buckets] = base1[keys1];
+    if (c == keys1 - 1 && threadIdx.x == 0) fine_base[fine_buckets] = base1[keys1];  // keys1 = number of groups of this pass
 }
 
 // tile-sorted scatter: every 4096-edge tile is ordered by key in LDS, then written as contiguous runs
@@ -508,20 +537,40 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     // ---- pass 2 ----
     if (p.two_pass) {
         PassArgs a2 = {};
-        a2.staged = w.staged_a; a2.seg_base = w.base1; a2.N = N; a2.shift = p.shift1; a2.sub_shift = p.node_shift; a2.keys = p.keys2;
+        a2.staged = w.staged_a; a2.seg_base = w.base1; a2.N = N; a2.shift = p.shift1; a2.sub_shift = p.shift2; a2.keys = p.keys2;
         a2.parts = p.parts2;
+        const int64_t buckets2 = p.three_pass ? p.groups3 : p.fine_buckets;  // buckets that exist after pass 2
         const unsigned blocks2 = (unsigned)(p.keys1 * p.parts2);
         hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks2), dim3(kThreads), 0, stream, a2, w.counts2, (int32_t *)nullptr,
                            (unsigned long long *)nullptr, (int32_t *)nullptr);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(scan_sub_counts_kernel, dim3(p.keys1), dim3(kThreads), 0, stream, w.counts2, p.keys2, p.parts2, w.base1,
-                           w.fine_base, p.fine_buckets, p.keys1);
+                           w.fine_base, buckets2, p.keys1);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks2), dim3(kThreads), 0, stream, a2, w.counts2, w.base1, w.staged_b,
                            (unsigned long long *)nullptr, (int32_t *)nullptr);
         SS_LAUNCH_CHECK();
         final_staged = w.staged_b;
         fine_base = w.fine_base;
+        // ---- pass 3 ----
+        if (p.three_pass) {
+            if (p.groups3 * p.parts3 >= ((int64_t)1 << 31)) return SS_ERR_UNSUPPORTED;
+            PassArgs a3 = {};
+            a3.staged = w.staged_b; a3.seg_base = w.fine_base; a3.N = N; a3.shift = p.shift2; a3.sub_shift = p.node_shift; a3.keys = p.keys3;
+            a3.parts = p.parts3;
+            const unsigned blocks3 = (unsigned)(p.groups3 * p.parts3);
+            hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks3), dim3(kThreads), 0, stream, a3, w.counts3, (int32_t *)nullptr,
+                               (unsigned long long *)nullptr, (int32_t *)nullptr);
+            SS_LAUNCH_CHECK();
+            hipLaunchKernelGGL(scan_sub_counts_kernel, dim3((unsigned)p.groups3), dim3(kThreads), 0, stream, w.counts3, p.keys3, p.parts3,
+                               w.fine_base, w.fine_base3, p.fine_buckets, (int)p.groups3);
+            SS_LAUNCH_CHECK();
+            hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks3), dim3(kThreads), 0, stream, a3, w.counts3, w.fine_base, w.staged_a,
+                               (unsigned long long *)nullptr, (int32_t *)nullptr);
+            SS_LAUNCH_CHECK();
+            final_staged = w.staged_a;
+            fine_base = w.fine_base3;
+        }
     }
     // ---- finish ----
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p.fine_buckets), dim3(kFinishThreads), 0, stream, final_staged, fine_base, p.node_shift,
