@@ -51,6 +51,48 @@ __device__ __forceinline__ u32x4 hll_walk(const uint8_t *__restrict__ hll_in, co
     return u32x4{ae.x | ao.x, ae.y | ao.y, ae.z | ao.z, ae.w | ao.w};
 }
 
+// the first <= 16 neighbours of a row walked by ONE 16-lane DPP row: lane c fetches neighbour id c (one coalesced 64-byte
+// load per row instead of one broadcast load per neighbour), the ids reach the other lanes through DPP row_newbcast, and
+// four row chunks are requested before the first is consumed
+template <int T0>
+__device__ __forceinline__ void hll_visit16(const uint8_t *__restrict__ hll_in, int my_nb, int deg, int count, int64_t self_row, int c,
+                                            u32x4 &ae, u32x4 &ao)
+{
+    if constexpr (T0 < 16) {
+        if (__any(T0 < count)) {  // wave-uniform: skip batches no lane group needs
+            u32x4 x[4];
+            const int nbt[4] = {__builtin_amdgcn_update_dpp(0, my_nb, 0x150 + T0, 0xF, 0xF, false),  // row_newbcast:T0 ..
+                                __builtin_amdgcn_update_dpp(0, my_nb, 0x150 + T0 + 1, 0xF, 0xF, false),
+                                __builtin_amdgcn_update_dpp(0, my_nb, 0x150 + T0 + 2, 0xF, 0xF, false),
+                                __builtin_amdgcn_update_dpp(0, my_nb, 0x150 + T0 + 3, 0xF, 0xF, false)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t j = T0 + k < deg ? (int64_t)nbt[k] : self_row;
+                x[k] = u32x4{0u, 0u, 0u, 0u};
+                if (T0 + k < count) x[k] = *reinterpret_cast<const u32x4 *>(hll_in + j * 256 + 16 * c);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ae.x = pk_max_u16(ae.x, x[k].x & 0x00FF00FFu); ao.x = pk_max_u16(ao.x, x[k].x & 0xFF00FF00u);
+                ae.y = pk_max_u16(ae.y, x[k].y & 0x00FF00FFu); ao.y = pk_max_u16(ao.y, x[k].y & 0xFF00FF00u);
+                ae.z = pk_max_u16(ae.z, x[k].z & 0x00FF00FFu); ao.z = pk_max_u16(ao.z, x[k].z & 0xFF00FF00u);
+                ae.w = pk_max_u16(ae.w, x[k].w & 0x00FF00FFu); ao.w = pk_max_u16(ao.w, x[k].w & 0xFF00FF00u);
+            }
+            hll_visit16<T0 + 4>(hll_in, my_nb, deg, count, self_row, c, ae, ao);
+        }
+    }
+}
+
+__device__ __forceinline__ u32x4 hll_walk_first16(const uint8_t *__restrict__ hll_in, const int32_t *__restrict__ nb, int deg, int total,
+                                                  int64_t self_row, int c)
+{
+    const int count = total < 16 ? total : 16;
+    const int my_nb = c < deg ? nb[c] : 0;
+    u32x4 ae = {0u, 0u, 0u, 0u}, ao = {0u, 0u, 0u, 0u};
+    hll_visit16<0>(hll_in, my_nb, deg, count, self_row, c, ae, ao);
+    return u32x4{ae.x | ao.x, ae.y | ao.y, ae.z | ao.z, ae.w | ao.w};
+}
+
 __device__ __forceinline__ uint32_t permuted_hash(uint64_t a, uint64_t b, uint64_t hv)
 {
     return (uint32_t)mod_mersenne61(a * hv + b);
@@ -232,7 +274,8 @@ __device__ __forceinline__ void hll_hop_row16(const GraphArgs &g, int64_t row, b
     // of max(degree) iterations -- skewed graphs put rows of 10 and of 500 neighbours into the same wavefront
     constexpr int kSolo = 32;
     const int32_t *nb = g.col + rb;
-    u32x4 acc = hll_walk(hll_in, nb, deg, total < kSolo ? total : kSolo, i, 0, 1, M, c);
+    u32x4 acc = hll_walk_first16(hll_in, nb, deg, total, i, c);
+    if (__any(total > 16)) acc = bytemax16(acc, hll_walk(hll_in, nb, deg, total < kSolo ? total : kSolo, i, 16, 1, M, c));
     const unsigned long long long_rows = __ballot(total > kSolo);
     if (long_rows) {
         const int grp = (threadIdx.x & (kWave - 1)) / kRow;
