@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
             const int c = cb + cl;
             const bool act = c < CM;
             u32x4 acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            if (act) acc = minhash_walk(mh_in, nb, deg, total, i, sg, G, P, c);
+            if constexpr (TP == 128) acc = minhash_walk128(mh_in, nb, deg, total, i, lane);
+            else if (act) acc = minhash_walk(mh_in, nb, deg, total, i, sg, G, P, c);
             for (int off = SG; off < kWave; off <<= 1) acc = min4(acc, shfl_xor4(acc, off));
             if (total == 0) acc = u32x4{0u, 0u, 0u, 0u};
             if (act && sg == 0) *reinterpret_cast<u32x4 *>(mh_out + i * P + 4 * c) = acc;

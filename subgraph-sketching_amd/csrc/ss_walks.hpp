@@ -34,6 +34,28 @@ __device__ __forceinline__ u32x4 minhash_walk(const uint32_t *__restrict__ mh_in
     return acc;
 }
 
+// P = 128 (two 32-lane subgroups, subgroup sg takes the neighbours t = sg, sg + 2, ...): the first <= 64 neighbour ids of
+// the row arrive with ONE coalesced load (lane l holds id l) and are handed out with v_readlane -- scalar, no memory
+// pipeline -- instead of one broadcast load per neighbour and subgroup; the rest of a longer row is walked as before
+__device__ __forceinline__ u32x4 minhash_walk128(const uint32_t *__restrict__ mh_in, const int32_t *__restrict__ nb, int deg, int total,
+                                                 int64_t self_row, int lane)
+{
+    const int sg = lane >> 5, c = lane & 31;
+    const int my_nb = lane < deg ? nb[lane] : 0;
+    const int head = total < kWave ? total : kWave;
+    u32x4 acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // one pair of neighbours per iteration, NOT batched: batches of 2 / 4 pairs (masked or clamped) measured 194-198 us
+    // against 187 us for this loop -- eight waves per SIMD already cover the latency, extra instructions only cost issue slots
+    for (int t0 = 0; t0 < head; t0 += 2) {  // wave-uniform trip count
+        const int s0 = __builtin_amdgcn_readlane(my_nb, t0), s1 = __builtin_amdgcn_readlane(my_nb, (t0 + 1) & (kWave - 1));
+        const int t = t0 + sg;
+        const int64_t j = t < deg ? (int64_t)(sg ? s1 : s0) : self_row;
+        if (t < head) acc = min4(acc, *reinterpret_cast<const u32x4 *>(mh_in + j * 128 + 4 * c));
+    }
+    if (total > kWave) acc = min4(acc, minhash_walk(mh_in, nb, deg, total, self_row, kWave + sg, 2, 128, c));
+    return acc;
+}
+
 // byte-wise max over the same neighbour walk of HLL chunk c; even / odd bytes accumulated as packed u16
 __device__ __forceinline__ u32x4 hll_walk(const uint8_t *__restrict__ hll_in, const int32_t *__restrict__ nb, int deg, int total,
                                           int64_t self_row, int first, int stride, int M, int c)
