@@ -170,6 +170,14 @@ int ss_pair_features_normalised(const int64_t *links, int64_t B, int64_t N, int3
 int ss_common_neighbour_scores(const int64_t *rowptr, const int32_t *col, const double *val, const double *mult,
                                int64_t N, const int64_t *links, int64_t B, float *out, int32_t *err_flag, void *stream);
 
+/* out = A * x for a row-grouped CSR with fp32 values -- the node-feature propagation of
+ * HashDataset._generate_sign_features (reference datasets/elph.py:87-110: gcn_norm, then torch_sparse.spmm = multiply
+ * and scatter-add in edge order).  Every output element is accumulated by one lane in CSR order, product and sum rounded
+ * separately, so with a CSR made by a STABLE sort of the reference's edge list the result equals the sequential
+ * scatter-add bit for bit.  rowptr: device int64[N+1]; col: int32[nnz]; val: fp32[nnz]; x, out: fp32 [N, F], F % 4 == 0. */
+int ss_spmm_csr(const int64_t *rowptr, const int32_t *col, const float *val, int64_t N, const float *x, int32_t F,
+                float *out, void *stream);
+
 /* int64 <-> packed uint32 MinHash tables (the reference's tensors are int64, hashing.py:124). */
 int ss_pack_minhash(const int64_t *in, uint32_t *out, int64_t count, void *stream);
 int ss_unpack_minhash(const uint32_t *in, int64_t *out, int64_t count, void *stream);

@@ -215,3 +215,33 @@ def common_neighbour_scores(A, links, kind):
     lib().so_common_neighbour_scores(_p(rowptr), _p(col), _p(val), _p(mult), c_int64(A.shape[0]), _p(links), c_int64(links.shape[0]),
                                      _p(out))
     return out
+
+
+def gcn_norm(edge_index, edge_weight, num_nodes):
+    """PyG gcn_norm defaults restated in numpy (PyG is absent here: unpinned): remaining self loops with weight 1 (existing
+    self loops keep theirs), symmetric normalisation by the weighted in-degree over edge_index[1]"""
+    ei = np.asarray(edge_index, dtype=np.int64).reshape(2, -1)
+    w = np.asarray(edge_weight, dtype=np.float32)
+    keep = ei[0] != ei[1]
+    loop_w = np.ones(num_nodes, dtype=np.float32)
+    loop_w[ei[0][~keep]] = w[~keep]
+    loops = np.arange(num_nodes, dtype=np.int64)
+    ei2 = np.concatenate([ei[:, keep], np.stack([loops, loops])], axis=1)
+    w2 = np.concatenate([w[keep], loop_w]).astype(np.float32)
+    deg = np.zeros(num_nodes, dtype=np.float32)
+    np.add.at(deg, ei2[1], w2)
+    with np.errstate(divide='ignore'):
+        dinv = np.power(deg, np.float32(-0.5)).astype(np.float32)
+    dinv[np.isinf(dinv)] = 0
+    return ei2, (dinv[ei2[0]] * w2 * dinv[ei2[1]]).astype(np.float32)
+
+
+def spmm(index, value, n, x):
+    """torch_sparse.spmm: sequential fp32 scatter-add of value * x[index[1]] into rows index[0]"""
+    row = np.ascontiguousarray(index[0], dtype=np.int64)
+    col = np.ascontiguousarray(index[1], dtype=np.int64)
+    val = np.ascontiguousarray(value, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty((n, x.shape[1]), dtype=np.float32)
+    lib().so_spmm_coo(_p(row), _p(col), _p(val), c_int64(row.size), c_int64(n), _p(x), c_int32(x.shape[1]), _p(out))
+    return out

@@ -366,3 +366,19 @@ void so_common_neighbour_scores(const int64_t *rowptr, const int32_t *col, const
         out[q] = (float)acc;
     }
 }
+
+/* torch_sparse.spmm as used by datasets/elph.py:87-110: out[row[e]] += val[e] * x[col[e]] for
+ * e = 0..E-1 in edge order, fp32 product and fp32 add rounded separately (sequential CPU scatter_add). */
+void so_spmm_coo(const int64_t *row, const int64_t *col, const float *val, int64_t E, int64_t N, const float *x, int32_t F, float *out)
+{
+    for (int64_t k = 0; k < N * F; ++k) out[k] = 0.0f;
+    for (int64_t e = 0; e < E; ++e) {
+        const float w = val[e];
+        const float *src = x + col[e] * F;
+        float *dst = out + row[e] * F;
+        for (int32_t f = 0; f < F; ++f) {
+            const float prod = src[f] * w;
+            dst[f] += prod;
+        }
+    }
+}

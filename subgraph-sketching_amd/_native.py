@@ -53,6 +53,7 @@ SIGNATURES = {
                                               c_void_p, c_void_p, c_void_p]),
     'ss_common_neighbour_scores': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                              c_void_p]),
+    'ss_spmm_csr': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     'ss_pack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_unpack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_profile_enable': (c_int32, [c_int32]),

@@ -227,3 +227,27 @@ def test_common_neighbour_heuristics_vs_reference():
         assert got.dtype == np.float32 and np.array_equal(got, g[kind]), kind
     for suffix in ('_float_weights', '_unit_weights'):
         assert np.array_equal(oracle.common_neighbour_scores(mats[suffix], g['links'], 'RA'), g['RA' + suffix]), suffix
+
+
+def test_sign_feature_propagation_restatement():
+    """gcn_norm + spmm (reference datasets/elph.py:87-110) have no golden vectors: PyG and torch_sparse are absent from this
+    image, so this row is PARITY UNPINNED.  What can be checked: the restated semantics against an independent dense fp64
+    evaluation of D^-1/2 (A + remaining self loops) D^-1/2 x."""
+    rng = np.random.RandomState(3)
+    n = 120
+    e = rng.randint(0, n, size=(2, 900))
+    e[:, :7] = np.array([[5, 5, 9, 9, 11, 40, 40], [5, 5, 9, 9, 11, 41, 41]])  # self loops (one duplicated) and a duplicate edge
+    w = rng.randint(1, 5, size=900).astype(np.float32)
+    ei, wn = oracle.gcn_norm(e, w, n)
+    x = rng.randn(n, 12).astype(np.float32)
+    got = oracle.spmm(ei, wn, n, x)
+    A = np.zeros((n, n))
+    keep = e[0] != e[1]
+    np.add.at(A, (e[0][keep], e[1][keep]), w[keep].astype(np.float64))
+    loop = np.ones(n)
+    loop[e[0][~keep]] = w[~keep]  # last listed weight of an existing self loop
+    A[np.arange(n), np.arange(n)] += loop
+    deg = A.sum(axis=0)
+    dinv = np.where(deg > 0, deg ** -0.5, 0.0)
+    want = (dinv[:, None] * A * dinv[None, :]) @ x.astype(np.float64)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
