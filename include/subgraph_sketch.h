@@ -84,6 +84,11 @@ typedef struct ss_csr_graph {
     int32_t reserved;
     const int32_t *hub_rows;          /* ... listed here (device int32[*hub_count], nullable) and processed by  */
     const int32_t *hub_count;         /* a 16-wave cooperative kernel instead of a single wavefront             */
+    const int32_t *mega_rows;         /* device int32[4 * max]: {row, first_slice, n_slices, done} per "mega row" */
+    const int32_t *mega_count;        /* device int32[2]: {mega rows, slices}.  Rows with more than SS_MEGA_SLICE   */
+    void *mega_scratch;               /* neighbours are walked slice by slice by ALL hub workgroups; the partial     */
+                                      /* rows go through mega_scratch (SS_MEGA_SLOT_BYTES each), the last slice to   */
+                                      /* finish combines them.  All three nullable together (then such rows are hub rows).  */
     int64_t row_begin;                /* destination rows [row_begin, row_end) are computed by ss_propagate /    */
     int64_t row_end;                  /* ss_first_hop (multi-GPU destination-range sharding);       */
                                       /* row_end == 0 means all rows.  Outputs are indexed by the GLOBAL row id.  */
@@ -100,9 +105,15 @@ typedef struct ss_csr_graph {
  *   err_flag: device int32 (nullable), set to 1 if any endpoint is outside [0, N) (such edges are dropped).
  * Workspace: ss_csr_workspace_bytes(N, E) bytes (0 = unsupported size).  No per-edge global atomics: a
  * two-level counting sort (LDS histograms per edge slice -> bucket offsets -> per-bucket LDS sort). */
+#define SS_MEGA_SLICE 4096      /* neighbours per slice of a mega row */
+#define SS_MEGA_SLOT_BYTES 1280 /* scratch per slice: partial MinHash row (<= 256 x u32) + partial HLL row (256 B) */
 size_t ss_csr_workspace_bytes(int64_t N, int64_t E);
+/* mega_rows / mega_count (nullable together): rows with more than max(hub_threshold, SS_MEGA_SLICE) in-edges are listed
+ * there instead of in hub_rows: mega_rows must hold 4 * (E / SS_MEGA_SLICE + 1) int32, mega_count 2 int32; the slices of
+ * all mega rows number at most 3 * (E / SS_MEGA_SLICE + 1) -- the scratch ss_csr_graph.mega_scratch needs SS_MEGA_SLOT_BYTES for each. */
 int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                  int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
+                 int32_t *mega_rows, int32_t *mega_count,
                  int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream);
 
 /* One hop of sketch propagation over a CSR: out[i] = min (MinHash) / max (HLL) over the in-neighbours

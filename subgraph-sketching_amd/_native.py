@@ -27,7 +27,11 @@ class CsrGraphStruct(ctypes.Structure):
     """mirror of `struct ss_csr_graph`"""
     _fields_ = [('rowptr', c_void_p), ('col', c_void_p), ('num_nodes', c_int64), ('n_self_loops', c_int64),
                 ('n_self_loops_dev', c_void_p), ('hub_threshold', c_int32), ('reserved', c_int32),
-                ('hub_rows', c_void_p), ('hub_count', c_void_p), ('row_begin', c_int64), ('row_end', c_int64)]
+                ('hub_rows', c_void_p), ('hub_count', c_void_p), ('mega_rows', c_void_p), ('mega_count', c_void_p),
+                ('mega_scratch', c_void_p), ('row_begin', c_int64), ('row_end', c_int64)]
+
+
+MEGA_SLICE, MEGA_SLOT_BYTES = 4096, 1280  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/subgraph_sketch.h
@@ -38,7 +42,7 @@ SIGNATURES = {
     'ss_hll_init': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'ss_csr_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'ss_csr_build': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_size_t, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ss_propagate': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p]),
     'ss_first_hop': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p, c_int32,

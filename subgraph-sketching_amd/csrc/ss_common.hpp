@@ -204,6 +204,30 @@ __device__ __forceinline__ EstimatorTables stage_tables(EstimatorLds &lds, const
     return t;
 }
 
+constexpr int kMegaSlot = SS_MEGA_SLOT_BYTES, kMegaHllOffset = 1024;
+
+// Cross-workgroup hand-off of the mega-row partials WITHOUT cache-wide fences: the 8 XCD L2s are not coherent with each
+// other, and a device-scope release / acquire fence (__threadfence) writes back and invalidates a whole L2 -- measured
+// 1.6 ms for 135 slices, slower than not slicing at all.  Device-scope relaxed atomics instead go to the coherence point
+// access by access; the ticket that publishes them is ordered behind them by a workgroup-scope fence (a wait, no flush).
+__device__ __forceinline__ void coherent_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t coherent_load(const uint32_t *p)
+{
+    return __hip_atomic_load(const_cast<uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coherent_store4(uint8_t *p, u32x4 v)
+{
+    uint32_t *q = reinterpret_cast<uint32_t *>(p);
+    coherent_store(q, v.x); coherent_store(q + 1, v.y); coherent_store(q + 2, v.z); coherent_store(q + 3, v.w);
+}
+__device__ __forceinline__ u32x4 coherent_load4(const uint8_t *p)
+{
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+    return u32x4{coherent_load(q), coherent_load(q + 1), coherent_load(q + 2), coherent_load(q + 3)};
+}
+// all stores of this workgroup have completed (been acknowledged) before anything that follows the next barrier
+__device__ __forceinline__ void workgroup_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+
 struct GraphArgs {  // device-side view of ss_csr_graph
     const int64_t *rowptr;
     const int32_t *col;
@@ -213,6 +237,9 @@ struct GraphArgs {  // device-side view of ss_csr_graph
     int hub_threshold;
     const int32_t *hub_rows;
     const int32_t *hub_count;
+    int32_t *mega_rows;        // int4 {row, first_slice, n_slices, done} per mega row (done: ticket counter, self-resetting)
+    const int32_t *mega_count;  // {mega rows, slices}
+    uint8_t *mega_scratch;      // kMegaSlot bytes per slice: partial MinHash row at 0, partial HLL row at kMegaHllOffset
     int64_t row0, row1;  // destination rows [row0, row1) are computed by this launch
     __host__ __device__ int64_t rows() const { return row1 - row0; }
     __device__ bool owns(int64_t i) const { return i >= row0 && i < row1; }
@@ -221,8 +248,10 @@ struct GraphArgs {  // device-side view of ss_csr_graph
 inline GraphArgs to_args(const ss_csr_graph &g)
 {
     const bool all = g.row_end == 0 && g.row_begin == 0;
+    const bool mega = g.mega_rows && g.mega_count && g.mega_scratch;
     return GraphArgs{g.rowptr, g.col, g.num_nodes, g.n_self_loops, g.n_self_loops_dev, g.hub_threshold, g.hub_rows, g.hub_count,
-                     all ? 0 : g.row_begin, all ? g.num_nodes : g.row_end};
+                     mega ? const_cast<int32_t *>(g.mega_rows) : nullptr, mega ? g.mega_count : nullptr,
+                     mega ? static_cast<uint8_t *>(g.mega_scratch) : nullptr, all ? 0 : g.row_begin, all ? g.num_nodes : g.row_end};
 }
 
 inline bool row_range_ok(const ss_csr_graph &g)

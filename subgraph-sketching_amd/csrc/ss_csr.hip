@@ -199,12 +199,14 @@ __device__ __forceinline__ int key_of(const PassArgs &a, int64_t d, int group)
 // counts[(group * keys + key) * parts + part]
 template <bool PASS2>
 __global__ __launch_bounds__(kThreads) void count_keys_kernel(PassArgs a, uint32_t *__restrict__ counts, int32_t *__restrict__ err,
-                                                              unsigned long long *__restrict__ n_self, int32_t *__restrict__ hub_count)
+                                                              unsigned long long *__restrict__ n_self, int32_t *__restrict__ hub_count,
+                                                              int32_t *__restrict__ mega_count)
 {
     __shared__ uint32_t hist[kMaxKeys];
     if (!PASS2 && blockIdx.x == 0 && threadIdx.x == 0) {  // outputs of later kernels of this build are cleared here
         *n_self = 0ULL;
         if (hub_count) *hub_count = 0;
+        if (mega_count) mega_count[0] = mega_count[1] = 0;
     }
     hist[threadIdx.x] = 0;
     __syncthreads();
@@ -393,7 +395,8 @@ __global__ __launch_bounds__(kThreads) void scatter_tiles_kernel(PassArgs a, con
 __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__restrict__ staged, const unsigned long long *__restrict__ fine_base,
                                                                 int node_shift, int64_t N, int64_t *__restrict__ rowptr,
                                                                 int32_t *__restrict__ col, int hub_threshold, int32_t *__restrict__ hub_rows,
-                                                                int32_t *__restrict__ hub_count)
+                                                                int32_t *__restrict__ hub_count, int32_t *__restrict__ mega_rows,
+                                                                int32_t *__restrict__ mega_count)
 {
     __shared__ uint32_t cnt[1024], excl[1024 + 1];
     __shared__ int32_t image[kFinishCap];  // LDS image of (a node sub-range of) the bucket's col segment
@@ -439,7 +442,16 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__re
             excl[b0 + k] = ex;
             if (node0 + b0 + k < N) {
                 rowptr[node0 + b0 + k] = (int64_t)(seg_lo + ex);
-                if (hub_rows && c > (uint32_t)hub_threshold) hub_rows[atomicAdd(hub_count, 1)] = (int32_t)(node0 + b0 + k);
+                if (hub_rows && c > (uint32_t)hub_threshold) {
+                    if (mega_rows && c > (uint32_t)SS_MEGA_SLICE) {  // walked slice by slice by all hub workgroups
+                        const int slices = (int)((c + 1 + SS_MEGA_SLICE - 1) / SS_MEGA_SLICE);  // + 1: the implicit self loop
+                        const int m = atomicAdd(&mega_count[0], 1);
+                        const int first = atomicAdd(&mega_count[1], slices);
+                        reinterpret_cast<int4 *>(mega_rows)[m] = make_int4((int)(node0 + b0 + k), first, slices, 0);
+                    } else {
+                        hub_rows[atomicAdd(hub_count, 1)] = (int32_t)(node0 + b0 + k);
+                    }
+                }
             }
             ex += c;
         }
@@ -501,12 +513,14 @@ extern "C" size_t ss_csr_workspace_bytes(int64_t N, int64_t E)
 
 extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                             int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
+                            int32_t *mega_rows, int32_t *mega_count,
                             int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_)
 {
     using namespace ss;
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || !rowptr) return SS_ERR_INVALID_ARG;
     if (E > 0 && (!src || !dst || !col)) return SS_ERR_INVALID_ARG;
     if ((hub_rows == nullptr) != (hub_count == nullptr)) return SS_ERR_INVALID_ARG;
+    if ((mega_rows == nullptr) != (mega_count == nullptr) || (mega_rows && !hub_rows)) return SS_ERR_INVALID_ARG;
     CsrPlan p;
     if (!make_plan(N, E, p)) return SS_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < ss_csr_workspace_bytes(N, E)) return SS_ERR_WORKSPACE;
@@ -514,6 +528,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     if (N == 0 || E == 0) {
         if (n_self_loops_out && hipMemsetAsync(n_self_loops_out, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
         if (hub_count && hipMemsetAsync(hub_count, 0, 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
+        if (mega_count && hipMemsetAsync(mega_count, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
         if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
         return SS_OK;
     }
@@ -523,7 +538,8 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     // ---- pass 1 ----
     PassArgs a1 = {};
     a1.src = src; a1.dst = dst; a1.E = E; a1.N = N; a1.slice = p.slice1; a1.shift = p.shift1; a1.keys = p.keys1;
-    hipLaunchKernelGGL(count_keys_kernel<false>, dim3(p.blocks1), dim3(kThreads), 0, stream, a1, w.counts1, err_flag, n_self, hub_count);
+    hipLaunchKernelGGL(count_keys_kernel<false>, dim3(p.blocks1), dim3(kThreads), 0, stream, a1, w.counts1, err_flag, n_self, hub_count,
+                       mega_count);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_block_counts_kernel, dim3((p.keys1 + 3) / 4), dim3(kThreads), 0, stream, w.counts1, p.blocks1, p.keys1, w.base1);
     SS_LAUNCH_CHECK();
@@ -542,7 +558,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
         const int64_t buckets2 = p.three_pass ? p.groups3 : p.fine_buckets;  // buckets that exist after pass 2
         const unsigned blocks2 = (unsigned)(p.keys1 * p.parts2);
         hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks2), dim3(kThreads), 0, stream, a2, w.counts2, (int32_t *)nullptr,
-                           (unsigned long long *)nullptr, (int32_t *)nullptr);
+                           (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(scan_sub_counts_kernel, dim3(p.keys1), dim3(kThreads), 0, stream, w.counts2, p.keys2, p.parts2, w.base1,
                            w.fine_base, buckets2, p.keys1);
@@ -560,7 +576,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
             a3.parts = p.parts3;
             const unsigned blocks3 = (unsigned)(p.groups3 * p.parts3);
             hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks3), dim3(kThreads), 0, stream, a3, w.counts3, (int32_t *)nullptr,
-                               (unsigned long long *)nullptr, (int32_t *)nullptr);
+                               (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
             SS_LAUNCH_CHECK();
             hipLaunchKernelGGL(scan_sub_counts_kernel, dim3((unsigned)p.groups3), dim3(kThreads), 0, stream, w.counts3, p.keys3, p.parts3,
                                w.fine_base, w.fine_base3, p.fine_buckets, (int)p.groups3);
@@ -574,7 +590,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     }
     // ---- finish ----
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p.fine_buckets), dim3(kFinishThreads), 0, stream, final_staged, fine_base, p.node_shift,
-                       N, rowptr, col, (int)hub_threshold, hub_rows, hub_count);
+                       N, rowptr, col, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -186,8 +186,10 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
     __shared__ EstimatorLds lds;
     __shared__ __attribute__((aligned(16))) uint32_t hll_row[256];
     __shared__ uint32_t mh_row[PPL * kWave];
+    __shared__ int s_last;
     const int n_hubs = *g.hub_count;
-    if ((int)blockIdx.x >= n_hubs) return;  // the common case (no hub rows) costs one scalar load per workgroup
+    const int n_mega = g.mega_count ? g.mega_count[0] : 0;
+    if ((int)blockIdx.x >= n_hubs && n_mega == 0) return;  // the common case (no hub rows) costs two scalar loads per workgroup
     const bool want_cards = DO_HLL && cards_out != nullptr;
     EstimatorTables est;
     if (want_cards) est = stage_tables(lds, prm);
@@ -201,46 +203,115 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
         b[q] = DO_MH ? pb[lane + kWave * q] : 0ULL;
     }
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
-    for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
-        const int64_t i = g.hub_rows[h];
-        if (!g.owns(i)) continue;  // workgroup-uniform
-        const int64_t rb = g.rowptr[i];
-        const int deg = (int)(g.rowptr[i + 1] - rb);
-        const int total = deg + (i < n_self ? 1 : 0);
+
+    // all 16 waves hash the neighbours t in [lo, hi) of row i (batches of 64, one batch per wave and step); the combined
+    // partial rows are left in mh_row / hll_row (LDS)
+    auto walk = [&](int64_t i, const int32_t *nb, int deg, int lo, int hi) {
         if (threadIdx.x < 256) hll_row[threadIdx.x] = 0u;
         if (threadIdx.x < P) mh_row[threadIdx.x] = 0xFFFFFFFFu;
         __syncthreads();
         uint32_t acc[PPL];
 #pragma unroll
         for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
-        first_hop_walk<PPL, DO_MH, DO_HLL>(g.col + rb, deg, total, i, wave, kHubWaves, p, a, b, acc, hll_row, lane);
+        // slice = the same walk over nb + lo with the degree counted from lo (slot deg - lo is the implicit self loop)
+        first_hop_walk<PPL, DO_MH, DO_HLL>(nb + lo, deg - lo, hi - lo, i, wave, kHubWaves, p, a, b, acc, hll_row, lane);
         if (DO_MH) {
 #pragma unroll
             for (int q = 0; q < PPL; ++q) atomicMin(&mh_row[lane + kWave * q], acc[q]);
         }
         __syncthreads();
-        if (wave == 0) {
-            if (DO_MH) {
+    };
+    // wave 0 stores the finished row (+ its cardinality): lane l holds MinHash values l, l + 64, .. and HLL registers 4l .. 4l+3
+    auto finish = [&](int64_t i, const uint32_t (&mh)[PPL], uint32_t regs) {
+        if (DO_MH) {
 #pragma unroll
-                for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = mh_row[lane + kWave * q];
+            for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = mh[q];
+        }
+        if (DO_HLL) *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
+        if (want_cards) {
+            int nonzero = 0;
+            float hsum = 0.0f;
+            hll_dword_stats(regs, nonzero, hsum);
+            for (int off = 1; off < kWave; off <<= 1) {
+                nonzero += __shfl_xor(nonzero, off);
+                hsum += __shfl_xor(hsum, off);
             }
-            uint32_t regs = 0;
-            if (DO_HLL) {
-                regs = pack_hll_quad(hll_row, lane);
-                *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
-            }
-            if (want_cards) {
-                int nonzero = 0;
-                float hsum = 0.0f;
-                hll_dword_stats(regs, nonzero, hsum);
-                for (int off = 1; off < kWave; off <<= 1) {
-                    nonzero += __shfl_xor(nonzero, off);
-                    hsum += __shfl_xor(hsum, off);
-                }
-                if (lane == 0) cards_out[i * cards_stride] = hll_estimate(est, 256 - nonzero, hsum);
-            }
+            if (lane == 0) cards_out[i * cards_stride] = hll_estimate(est, 256 - nonzero, hsum);
+        }
+    };
+
+    for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
+        const int64_t i = g.hub_rows[h];
+        if (!g.owns(i)) continue;  // workgroup-uniform
+        const int64_t rb = g.rowptr[i];
+        const int deg = (int)(g.rowptr[i + 1] - rb);
+        const int total = deg + (i < n_self ? 1 : 0);
+        walk(i, g.col + rb, deg, 0, total);
+        if (wave == 0) {
+            uint32_t mh[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) mh[q] = DO_MH ? mh_row[lane + kWave * q] : 0u;
+            finish(i, mh, DO_HLL ? pack_hll_quad(hll_row, lane) : 0u);
         }
         __syncthreads();
+    }
+
+    // ---- mega rows: slices of SS_MEGA_SLICE neighbours spread over all workgroups, combined by the last one to finish
+    // (see propagate_hub_kernel); scratch layout per slice: MinHash u32[P] (P <= 256: within the first 1024 B ... P = 128
+    // uses 512 B) then the packed HLL row at byte 512
+    for (int m = 0; m < n_mega; ++m) {
+        const int4 e = reinterpret_cast<const int4 *>(g.mega_rows)[m];
+        const int64_t i = e.x;
+        if (!g.owns(i)) continue;
+        const int64_t rb = g.rowptr[i];
+        const int deg = (int)(g.rowptr[i + 1] - rb);
+        const int total = deg + (i < n_self ? 1 : 0);
+        // global slice g = e.y + sl belongs to workgroup g % gridDim.x: the slices of ALL mega rows are dealt round robin
+        // (dealing each row's slices from workgroup 0 would give the low-numbered workgroups one slice of every row)
+        for (int sl = (int)((blockIdx.x + gridDim.x - (unsigned)e.y % gridDim.x) % gridDim.x); sl < e.z; sl += gridDim.x) {
+            const int lo = sl * SS_MEGA_SLICE < total ? sl * SS_MEGA_SLICE : total;
+            const int hi = lo + SS_MEGA_SLICE < total ? lo + SS_MEGA_SLICE : total;
+            walk(i, g.col + rb, deg, lo, hi);
+            uint8_t *mine = g.mega_scratch + (int64_t)(e.y + sl) * kMegaSlot;
+            if (wave == 0) {
+                if (DO_MH) {
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) coherent_store(reinterpret_cast<uint32_t *>(mine) + lane + kWave * q, mh_row[lane + kWave * q]);
+                }
+                if (DO_HLL) coherent_store(reinterpret_cast<uint32_t *>(mine + kMegaHllOffset) + lane, pack_hll_quad(hll_row, lane));
+            }
+            workgroup_release();  // see ss_common.hpp: no cache-wide fence
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int prev = atomicAdd(&g.mega_rows[4 * m + 3], 1);
+                s_last = prev == e.z - 1;
+                if (s_last) g.mega_rows[4 * m + 3] = 0;
+            }
+            __syncthreads();
+            if (s_last) {
+                if (wave == 0) {
+                    uint32_t mh[PPL], regs = 0u;
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) mh[q] = 0xFFFFFFFFu;
+                    for (int s2 = 0; s2 < e.z; ++s2) {
+                        const uint8_t *part = g.mega_scratch + (int64_t)(e.y + s2) * kMegaSlot;
+                        if (DO_MH) {
+#pragma unroll
+                            for (int q = 0; q < PPL; ++q) {
+                                const uint32_t v = coherent_load(reinterpret_cast<const uint32_t *>(part) + lane + kWave * q);
+                                mh[q] = v < mh[q] ? v : mh[q];
+                            }
+                        }
+                        if (DO_HLL) {
+                            const uint32_t v = coherent_load(reinterpret_cast<const uint32_t *>(part + kMegaHllOffset) + lane);
+                            regs = pk_max_u16(regs & 0x00FF00FFu, v & 0x00FF00FFu) | pk_max_u16(regs & 0xFF00FF00u, v & 0xFF00FF00u);
+                        }
+                    }
+                    finish(i, mh, regs);
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 

@@ -147,8 +147,10 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
     __shared__ EstimatorLds lds;
     __shared__ u32x4 part_mh[kHubWaves][CM];
     __shared__ u32x4 part_hll[kHubWaves][CH];
+    __shared__ int s_last;
     const int n_hubs = *g.hub_count;
-    if ((int)blockIdx.x >= n_hubs) return;  // the common case (no hub rows) costs one scalar load per workgroup
+    const int n_mega = g.mega_count ? g.mega_count[0] : 0;
+    if ((int)blockIdx.x >= n_hubs && n_mega == 0) return;  // the common case (no hub rows) costs two scalar loads per workgroup
     const bool want_cards = cards_out != nullptr && hll_out != nullptr;
     EstimatorTables est;
     if (want_cards) est = stage_tables(lds, prm);
@@ -156,22 +158,18 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
 
-    for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
-        const int64_t i = g.hub_rows[h];
-        if (!g.owns(i)) continue;  // workgroup-uniform
-        const int64_t rb = g.rowptr[i];
-        const int deg = (int)(g.rowptr[i + 1] - rb);
-        const int total = deg + (i < n_self ? 1 : 0);
-        const int32_t *nb = g.col + rb;
+    // all 16 waves walk the neighbours t in [lo, hi) of row i; wave 0 ends up with the combined partial rows
+    // (MinHash chunk `lane` in lanes 0..31, HLL chunk `lane - 32` in lanes 32..47)
+    auto walk = [&](int64_t i, const int32_t *nb, int deg, int lo, int hi, u32x4 &mh_acc, u32x4 &hll_acc) {
         if (mh_out) {
             const int sg = lane >> 5, c = lane & 31;
-            u32x4 acc = minhash_walk(mh_in, nb, deg, total, i, wave * 2 + sg, kHubWaves * 2, P, c);
+            u32x4 acc = minhash_walk(mh_in, nb, deg, hi, i, lo + wave * 2 + sg, kHubWaves * 2, P, c);
             acc = min4(acc, shfl_xor4(acc, 32));
             if (sg == 0) part_mh[wave][c] = acc;
         }
         if (hll_out) {
             const int sg = lane >> 4, c = lane & 15;
-            u32x4 acc = hll_walk(hll_in, nb, deg, total, i, wave * 4 + sg, kHubWaves * 4, M, c);
+            u32x4 acc = hll_walk(hll_in, nb, deg, hi, i, lo + wave * 4 + sg, kHubWaves * 4, M, c);
             acc = bytemax16(acc, shfl_xor4(acc, 16));
             acc = bytemax16(acc, shfl_xor4(acc, 32));
             if (sg == 0) part_hll[wave][c] = acc;
@@ -179,31 +177,93 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
         __syncthreads();
         if (wave == 0) {
             if (mh_out && lane < CM) {
-                u32x4 acc = part_mh[0][lane];
+                mh_acc = part_mh[0][lane];
 #pragma unroll
-                for (int w = 1; w < kHubWaves; ++w) acc = min4(acc, part_mh[w][lane]);
-                *reinterpret_cast<u32x4 *>(mh_out + i * P + 4 * lane) = acc;
+                for (int w = 1; w < kHubWaves; ++w) mh_acc = min4(mh_acc, part_mh[w][lane]);
             }
-            if (hll_out && lane >= 32 && lane < 32 + CH) {  // lanes 32..47 = one DPP row
-                const int c = lane - 32;
-                u32x4 acc = part_hll[0][c];
+            if (hll_out && lane >= 32 && lane < 32 + CH) {
+                hll_acc = part_hll[0][lane - 32];
 #pragma unroll
-                for (int w = 1; w < kHubWaves; ++w) acc = bytemax16(acc, part_hll[w][c]);
-                *reinterpret_cast<u32x4 *>(hll_out + i * M + 16 * c) = acc;
-                if (want_cards) {
-                    int nonzero = 0;
-                    float hsum = 0.0f;
-                    hll_dword_stats(acc.x, nonzero, hsum);
-                    hll_dword_stats(acc.y, nonzero, hsum);
-                    hll_dword_stats(acc.z, nonzero, hsum);
-                    hll_dword_stats(acc.w, nonzero, hsum);
-                    nonzero = row16_sum_i(nonzero);
-                    hsum = row16_sum_f(hsum);
-                    if (c == 0) cards_out[i * cards_stride] = hll_estimate(est, M - nonzero, hsum);
-                }
+                for (int w = 1; w < kHubWaves; ++w) hll_acc = bytemax16(hll_acc, part_hll[w][lane - 32]);
             }
         }
+    };
+    // wave 0 stores the finished row (+ its cardinality)
+    auto finish = [&](int64_t i, u32x4 mh_acc, u32x4 hll_acc) {
+        if (mh_out && lane < CM) *reinterpret_cast<u32x4 *>(mh_out + i * P + 4 * lane) = mh_acc;
+        if (hll_out && lane >= 32 && lane < 32 + CH) {  // lanes 32..47 = one DPP row
+            const int c = lane - 32;
+            *reinterpret_cast<u32x4 *>(hll_out + i * M + 16 * c) = hll_acc;
+            if (want_cards) {
+                int nonzero = 0;
+                float hsum = 0.0f;
+                hll_dword_stats(hll_acc.x, nonzero, hsum);
+                hll_dword_stats(hll_acc.y, nonzero, hsum);
+                hll_dword_stats(hll_acc.z, nonzero, hsum);
+                hll_dword_stats(hll_acc.w, nonzero, hsum);
+                nonzero = row16_sum_i(nonzero);
+                hsum = row16_sum_f(hsum);
+                if (c == 0) cards_out[i * cards_stride] = hll_estimate(est, M - nonzero, hsum);
+            }
+        }
+    };
+
+    for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
+        const int64_t i = g.hub_rows[h];
+        if (!g.owns(i)) continue;  // workgroup-uniform
+        const int64_t rb = g.rowptr[i];
+        const int deg = (int)(g.rowptr[i + 1] - rb);
+        const int total = deg + (i < n_self ? 1 : 0);
+        u32x4 mh_acc = {0u, 0u, 0u, 0u}, hll_acc = {0u, 0u, 0u, 0u};
+        walk(i, g.col + rb, deg, 0, total, mh_acc, hll_acc);
+        if (wave == 0) finish(i, mh_acc, hll_acc);
         __syncthreads();
+    }
+
+    // ---- mega rows: every workgroup takes slices of SS_MEGA_SLICE neighbours of every mega row; the partial rows go
+    // through mega_scratch and the workgroup that finishes a row's LAST slice (ticket counter) combines them.  A row
+    // with a million neighbours is spread over the whole chip instead of being one workgroup's serial walk.
+    for (int m = 0; m < n_mega; ++m) {
+        const int4 e = reinterpret_cast<const int4 *>(g.mega_rows)[m];  // {row, first slice, slices, ticket}
+        const int64_t i = e.x;
+        if (!g.owns(i)) continue;
+        const int64_t rb = g.rowptr[i];
+        const int deg = (int)(g.rowptr[i + 1] - rb);
+        const int total = deg + (i < n_self ? 1 : 0);
+        // global slice g = e.y + sl belongs to workgroup g % gridDim.x: the slices of ALL mega rows are dealt round robin
+        // (dealing each row's slices from workgroup 0 would give the low-numbered workgroups one slice of every row)
+        for (int sl = (int)((blockIdx.x + gridDim.x - (unsigned)e.y % gridDim.x) % gridDim.x); sl < e.z; sl += gridDim.x) {
+            const int lo = sl * SS_MEGA_SLICE < total ? sl * SS_MEGA_SLICE : total;
+            const int hi = lo + SS_MEGA_SLICE < total ? lo + SS_MEGA_SLICE : total;
+            u32x4 mh_acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hll_acc = {0u, 0u, 0u, 0u};
+            walk(i, g.col + rb, deg, lo, hi, mh_acc, hll_acc);
+            uint8_t *mine = g.mega_scratch + (int64_t)(e.y + sl) * kMegaSlot;
+            if (wave == 0) {
+                if (mh_out && lane < CM) coherent_store4(mine + 16 * lane, mh_acc);
+                if (hll_out && lane >= 32 && lane < 32 + CH) coherent_store4(mine + kMegaHllOffset + 16 * (lane - 32), hll_acc);
+            }
+            workgroup_release();  // the partial row has reached the coherence point before the ticket is taken
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int prev = atomicAdd(&g.mega_rows[4 * m + 3], 1);
+                s_last = prev == e.z - 1;
+                if (s_last) g.mega_rows[4 * m + 3] = 0;  // every slice has arrived: ready for the next hop
+            }
+            __syncthreads();
+            if (s_last) {
+                if (wave == 0) {
+                    u32x4 mh_all = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hll_all = {0u, 0u, 0u, 0u};
+                    for (int q = 0; q < e.z; ++q) {
+                        const uint8_t *part = g.mega_scratch + (int64_t)(e.y + q) * kMegaSlot;
+                        if (mh_out && lane < CM) mh_all = min4(mh_all, coherent_load4(part + 16 * lane));
+                        if (hll_out && lane >= 32 && lane < 32 + CH)
+                            hll_all = bytemax16(hll_all, coherent_load4(part + kMegaHllOffset + 16 * (lane - 32)));
+                    }
+                    finish(i, mh_all, hll_all);
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 

@@ -381,9 +381,10 @@ class CsrGraph(object):
     says whether the propagation adds those implicit self loops (build_hash_tables) or none (hll_prop / minhash_prop
     receive them explicitly in edge_index)."""
 
-    def __init__(self, rowptr, col, num_nodes, n_self_dev, err, hub_rows, hub_count, hub_threshold):
+    def __init__(self, rowptr, col, num_nodes, n_self_dev, err, hub_rows, hub_count, hub_threshold, mega=None):
         self.rowptr, self.col, self.num_nodes, self.n_self_dev, self.err = rowptr, col, num_nodes, n_self_dev, err
         self.hub_rows, self.hub_count, self.hub_threshold = hub_rows, hub_count, hub_threshold
+        self.mega_rows, self.mega_count, self.mega_scratch = mega if mega is not None else (None, None, None)
         self.use_inferred_self_loops = False
 
     def struct(self, rows=None):
@@ -395,7 +396,11 @@ class CsrGraph(object):
                                       n_self_loops=0,
                                       n_self_loops_dev=self.n_self_dev.data_ptr() if self.use_inferred_self_loops else None,
                                       hub_threshold=self.hub_threshold, reserved=0, hub_rows=self.hub_rows.data_ptr(),
-                                      hub_count=self.hub_count.data_ptr(), row_begin=begin, row_end=end)
+                                      hub_count=self.hub_count.data_ptr(),
+                                      mega_rows=self.mega_rows.data_ptr() if self.mega_rows is not None else None,
+                                      mega_count=self.mega_count.data_ptr() if self.mega_count is not None else None,
+                                      mega_scratch=self.mega_scratch.data_ptr() if self.mega_scratch is not None else None,
+                                      row_begin=begin, row_end=end)
 
 
 def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
@@ -416,17 +421,25 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
     hub_count = flags[1:2].view(torch.int32)[0:1]
     err = _error_flag(device)
     hub_rows = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=device)
+    # rows with more than SS_MEGA_SLICE in-edges ("mega rows") are walked slice by slice by all hub workgroups: list +
+    # counters + one scratch slot per slice (a row has > MEGA_SLICE edges, so there are at most E / MEGA_SLICE of them and
+    # at most three times as many slices)
+    max_mega = E // _native.MEGA_SLICE + 1
+    mega_rows = torch.empty((max_mega, 4), dtype=torch.int32, device=device)
+    mega_count = torch.empty(2, dtype=torch.int32, device=device)
+    mega_scratch = torch.empty(3 * max_mega * _native.MEGA_SLOT_BYTES, dtype=torch.uint8, device=device)
     ws_bytes = lib.ss_csr_workspace_bytes(num_nodes, E)
     if ws_bytes == 0:
         raise NotImplementedError(f'graphs with {num_nodes} nodes are not supported by the CSR builder')
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
     with _Span('csr_build', device):
         _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(n_self_dev),
-                                       hub_threshold, _ptr(hub_rows), _ptr(hub_count), _ptr(err), _ptr(ws), ws_bytes,
-                                       _stream(device)), 'ss_csr_build')
+                                       hub_threshold, _ptr(hub_rows), _ptr(hub_count), _ptr(mega_rows), _ptr(mega_count), _ptr(err),
+                                       _ptr(ws), ws_bytes, _stream(device)), 'ss_csr_build')
     if check and _take_error(device):
         raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
-    return CsrGraph(rowptr, col, num_nodes, n_self_dev, err, hub_rows, hub_count, hub_threshold)
+    return CsrGraph(rowptr, col, num_nodes, n_self_dev, err, hub_rows, hub_count, hub_threshold,
+                    mega=(mega_rows, mega_count, mega_scratch))
 
 
 class _CsrCache(object):
