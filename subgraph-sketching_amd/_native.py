@@ -31,6 +31,7 @@ class CsrGraphStruct(ctypes.Structure):
                 ('mega_scratch', c_void_p), ('row_begin', c_int64), ('row_end', c_int64)]
 
 
+ABI_VERSION = 110  # ss_version() of the library this module's struct mirrors and signatures describe
 MEGA_SLICE, MEGA_SLOT_BYTES = 4096, 1280  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
 
 
@@ -90,6 +91,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.ss_version() != ABI_VERSION:  # a stale in-tree build with another struct layout would corrupt launches
+            raise NativeLibraryMissing(f'{LIB_PATH} is version {handle.ss_version()}, this package needs {ABI_VERSION}: '
+                                       f'rebuild with `python __graft_entry__.py`')
         _lib = handle
     return _lib
 

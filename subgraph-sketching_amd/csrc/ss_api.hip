@@ -2,7 +2,7 @@
 // roofline figure: events are recorded on the very stream the kernel is launched on).
 #include "ss_common.hpp"
 
-extern "C" int ss_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int ss_version(void) { return 110; /* 0.1.1: ss_csr_graph row ranges + mega rows, ss_csr_build mega outputs, heuristics / spmm entry points */ }
 
 extern "C" const char *ss_error_string(int code)
 {
