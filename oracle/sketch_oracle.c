@@ -259,7 +259,7 @@ void so_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
 #pragma omp for schedule(static)
         for (int64_t q = 0; q < B; ++q) {
             const int64_t u = wrap_index(links[2 * q], N), v = wrap_index(links[2 * q + 1], N);
-            float I[4][4]; /* I[k1][k2], 1-based */
+            float I[4][4] = {{0.0f}}; /* I[k1][k2], 1-based */
             for (int k1 = 1; k1 <= h; ++k1)
                 for (int k2 = 1; k2 <= h; ++k2) {
                     const uint32_t *a = mh[k1 - 1] + u * P, *b = mh[k2 - 1] + v * P;
