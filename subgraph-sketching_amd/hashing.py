@@ -385,6 +385,7 @@ class CsrGraph(object):
         self.rowptr, self.col, self.num_nodes, self.n_self_dev, self.err = rowptr, col, num_nodes, n_self_dev, err
         self.hub_rows, self.hub_count, self.hub_threshold = hub_rows, hub_count, hub_threshold
         self.mega_rows, self.mega_count, self.mega_scratch = mega if mega is not None else (None, None, None)
+        self.has_hub_rows = True  # unknown (no host read of the device counters): keep the hub passes
         self.use_inferred_self_loops = False
 
     def struct(self, rows=None):
@@ -392,14 +393,17 @@ class CsrGraph(object):
         begin, end = (0, 0) if rows is None else rows
         if rows is not None and end == 0:  # (0, 0) would mean "all rows" to the library: express the empty range at N
             begin = end = self.num_nodes
+        hubs = self.has_hub_rows
+        mega = hubs and self.mega_rows is not None
         return _native.CsrGraphStruct(rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(), num_nodes=self.num_nodes,
                                       n_self_loops=0,
                                       n_self_loops_dev=self.n_self_dev.data_ptr() if self.use_inferred_self_loops else None,
-                                      hub_threshold=self.hub_threshold, reserved=0, hub_rows=self.hub_rows.data_ptr(),
-                                      hub_count=self.hub_count.data_ptr(),
-                                      mega_rows=self.mega_rows.data_ptr() if self.mega_rows is not None else None,
-                                      mega_count=self.mega_count.data_ptr() if self.mega_count is not None else None,
-                                      mega_scratch=self.mega_scratch.data_ptr() if self.mega_scratch is not None else None,
+                                      hub_threshold=self.hub_threshold, reserved=0,
+                                      hub_rows=self.hub_rows.data_ptr() if hubs else None,
+                                      hub_count=self.hub_count.data_ptr() if hubs else None,
+                                      mega_rows=self.mega_rows.data_ptr() if mega else None,
+                                      mega_count=self.mega_count.data_ptr() if mega else None,
+                                      mega_scratch=self.mega_scratch.data_ptr() if mega else None,
                                       row_begin=begin, row_end=end)
 
 
@@ -416,17 +420,21 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
         hub_threshold = HUB_THRESHOLD if HUB_THRESHOLD is not None else default_hub_threshold(E)
     rowptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=device)
     col = torch.empty(max(E, 1), dtype=torch.int32, device=device)
-    flags = torch.empty(2, dtype=torch.int64, device=device)  # [0] = n_self, [1] = hub count (both cleared by the kernels)
+    # one small block of device counters, all cleared by the kernels: int64 n_self | int32 hub rows, error | int32 mega rows, slices
+    flags = torch.empty(3, dtype=torch.int64, device=device)
+    flags32 = flags.view(torch.int32)
     n_self_dev = flags[0:1]
-    hub_count = flags[1:2].view(torch.int32)[0:1]
-    err = _error_flag(device)
+    hub_count = flags32[2:3]
+    mega_count = flags32[4:6]
+    err = flags32[3:4] if check else _error_flag(device)  # strict mode reads its own flag together with the counters below
+    if check:
+        err.zero_()
     hub_rows = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=device)
     # rows with more than SS_MEGA_SLICE in-edges ("mega rows") are walked slice by slice by all hub workgroups: list +
     # counters + one scratch slot per slice (a row has > MEGA_SLICE edges, so there are at most E / MEGA_SLICE of them and
     # at most three times as many slices)
     max_mega = E // _native.MEGA_SLICE + 1
     mega_rows = torch.empty((max_mega, 4), dtype=torch.int32, device=device)
-    mega_count = torch.empty(2, dtype=torch.int32, device=device)
     mega_scratch = torch.empty(3 * max_mega * _native.MEGA_SLOT_BYTES, dtype=torch.uint8, device=device)
     ws_bytes = lib.ss_csr_workspace_bytes(num_nodes, E)
     if ws_bytes == 0:
@@ -436,10 +444,16 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
         _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(n_self_dev),
                                        hub_threshold, _ptr(hub_rows), _ptr(hub_count), _ptr(mega_rows), _ptr(mega_count), _ptr(err),
                                        _ptr(ws), ws_bytes, _stream(device)), 'ss_csr_build')
-    if check and _take_error(device):
-        raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
-    return CsrGraph(rowptr, col, num_nodes, n_self_dev, err, hub_rows, hub_count, hub_threshold,
-                    mega=(mega_rows, mega_count, mega_scratch))
+    csr = CsrGraph(rowptr, col, num_nodes, n_self_dev, _error_flag(device), hub_rows, hub_count, hub_threshold,
+                   mega=(mega_rows, mega_count, mega_scratch))
+    if check:
+        # the one synchronising read of strict mode brings the hub / mega row counts along: a graph without such rows
+        # (every unskewed graph) then skips both hub-pass launches of every hop (4 us each)
+        host = flags32.cpu()
+        if int(host[3]):
+            raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
+        csr.has_hub_rows = bool(int(host[2]) or int(host[4]))
+    return csr
 
 
 class _CsrCache(object):
