@@ -462,14 +462,15 @@ class _CsrCache(object):
     self-looped edge_index object; this builds its CSR once per forward.  A dead weak reference or a
     bumped `_version` (in-place edit) invalidates the entry, so recycled allocations are never trusted."""
 
-    def __init__(self):
+    def __init__(self, check=lambda: True):
         self._ref, self._version, self._key, self._csr = None, None, None, None
+        self._check = check  # whether a build may synchronise to raise IndexError (ElphHashes.strict_bounds of the owner)
 
     def get(self, edge_index, num_nodes, device):
         key = (num_nodes, tuple(edge_index.shape), str(device))
         if self._ref is not None and self._ref() is edge_index and self._version == edge_index._version and self._key == key:
             return self._csr
-        csr = build_csr(edge_index, num_nodes, device, check=True)
+        csr = build_csr(edge_index, num_nodes, device, check=bool(self._check()))
         self._ref, self._version, self._key, self._csr = weakref.ref(edge_index), edge_index._version, key, csr
         return csr
 
@@ -600,7 +601,7 @@ class ElphHashes(object):
         self._minhash_range = (1 << 32)
         self.minhash_seed = 1
         self.num_perm = args.minhash_num_perm
-        self._csr_cache = _CsrCache()
+        self._csr_cache = _CsrCache(lambda: self.strict_bounds)
         self.minhash_prop = MinhashPropagation(self._csr_cache)
         # hll params (reference hashing.py:65-81)
         self.p = args.hll_p
@@ -632,7 +633,7 @@ class ElphHashes(object):
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        self._csr_cache = _CsrCache()
+        self._csr_cache = _CsrCache(lambda: self.strict_bounds)
         self.minhash_prop = MinhashPropagation(self._csr_cache)
         self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m)
 
