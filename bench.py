@@ -190,20 +190,22 @@ def main():
     # the per-batch feature gather runs on RCCL's stream UNDER the next step's build (double-buffered); every gather is
     # completed inside the timed region (drain() before the closing fence)
     gathered = [torch.empty((world * BATCH, H * (H + 2)), dtype=torch.float32, device=dev) for _ in range(2)] if launched else None
-    inflight = {'work': None, 'src': None, 'n': 0}
+    inflight = {'works': [], 'n': 0}
 
     def gather(f):
         if not launched:
             return
-        drain()  # the previous gather (issued one step ago) has long finished; frees its buffer for the one after next
-        inflight['work'] = dist.all_gather_into_tensor(gathered[inflight['n'] % 2], f, async_op=True)
-        inflight['src'] = f
+        # collectives of one process group run in issue order on RCCL's stream, so the buffer written two gathers ago is free
+        # again without the compute stream ever waiting for a gather; torch keeps `f` alive (record_stream) until it was read
+        inflight['works'].append((dist.all_gather_into_tensor(gathered[inflight['n'] % 2], f, async_op=True), f))
         inflight['n'] += 1
+        if len(inflight['works']) > 4:  # host-side bookkeeping only: the oldest ones finished steps ago
+            inflight['works'].pop(0)[0].wait()
 
     def drain():
-        if inflight['work'] is not None:
-            inflight['work'].wait()
-            inflight['work'], inflight['src'] = None, None
+        for work, _ in inflight['works']:
+            work.wait()
+        inflight['works'].clear()
 
     sharded_build = launched and world > 1 and a.build == 'sharded'
 
