@@ -162,3 +162,27 @@ def test_datasketch_tables_are_used_when_importable(ssa, monkeypatch):
     eh = ssa.ElphHashes(_args())
     assert eh.hll_tables.provenance == 'datasketch' and eh.alpha == 0.5 and eh.estimate_vector.shape == (84,)
     assert ssa.hll_tables.load(8, prefer='regenerated').provenance == 'regenerated'
+
+
+def test_adaptive_hub_threshold():
+    """E / 16384 clamped to [128, 1024]: the shapes of BASELINE.json's configs"""
+    from subgraph_sketching_amd.hashing import default_hub_threshold
+    assert default_hub_threshold(0) == 128 and default_hub_threshold(10138) == 128            # Cora
+    assert default_hub_threshold(2358104 + 235868) == 158 and default_hub_threshold(2358104) == 143   # collab with / without loops
+    assert default_hub_threshold(42463862) == 1024 and default_hub_threshold(60775990) == 1024   # ppa, citation2
+    assert all(128 <= default_hub_threshold(e) <= 1024 for e in (1, 10 ** 5, 10 ** 7, 10 ** 10))
+
+
+def test_abi_constants_match_the_header():
+    import re
+    from conftest import REPO
+    import os
+    from subgraph_sketching_amd import _native
+    text = open(os.path.join(REPO, 'include', 'subgraph_sketch.h')).read()
+    assert int(re.search(r'#define SS_MEGA_SLICE (\d+)', text).group(1)) == _native.MEGA_SLICE
+    assert int(re.search(r'#define SS_MEGA_SLOT_BYTES (\d+)', text).group(1)) == _native.MEGA_SLOT_BYTES
+    api = open(os.path.join(REPO, 'subgraph-sketching_amd', 'csrc', 'ss_api.hip')).read()
+    assert int(re.search(r'ss_version\(void\) \{ return (\d+);', api).group(1)) == _native.ABI_VERSION
+    fields = re.search(r'typedef struct ss_csr_graph \{(.*?)\} ss_csr_graph;', text, re.S).group(1)
+    names = re.findall(r'(\w+);', re.sub(r'/\*.*?\*/', '', fields, flags=re.S))
+    assert names == [f[0] for f in _native.CsrGraphStruct._fields_]   # the ctypes mirror lists the same fields in the same order
