@@ -1,6 +1,6 @@
 """stress: GPU engine vs the C oracle on many seeded collab-sized graphs (rare paths of the two-phase first hop: keys that
 share a 64-wide bucket, low words within 8 of 2^32 -- about one per 3*10^8 hashes --, duplicate neighbours).
-usage: python tools/stress_parity.py [n_seeds]"""
+usage: python tests/stress_parity.py [n_seeds]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
