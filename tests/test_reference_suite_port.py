@@ -1,7 +1,9 @@
 """The reference's own hot-path test strategy (/root/reference/test/test_hashing.py) run against
 the MI355X engine: a small Barabasi-Albert graph, ground truth from brute-force neighbour sets, tolerance-based
 assertions on cardinalities / intersections / features plus the exact structural and self-consistency checks.
-Each test names the reference test it mirrors.  Needs a GPU (`-m gpu`)."""
+Each test names the reference test it mirrors.  Not mirrored: test_minhash / test_hyperloglog (:35-60) -- they only print
+estimates of datasketch's own MinHash / HyperLogLogPlusPlus classes and assert nothing about src/hashing.py.
+Needs a GPU (`-m gpu`)."""
 from argparse import Namespace
 from math import isclose
 
