@@ -274,7 +274,7 @@ def main():
     timer = KernelTimer(None if a.time_all_kernels else set())
     hashing.KERNEL_TIMER = timer
     lib = ssa._native.lib()
-    lib.ss_profile_enable(1)  # HIP events around every launch of the dominant kernel (MinHash table hop), on its stream
+    lib.ss_profile_enable(1 << ssa._native.PROF_MINHASH_HOP)  # HIP events around every launch of the dominant kernel (MinHash table hop), on its stream
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -284,7 +284,7 @@ def main():
     hashing.KERNEL_TIMER = None
     from ctypes import byref, c_float, c_int32
     dom_ms, dom_n = c_float(), c_int32()
-    lib.ss_profile_read(byref(dom_ms), byref(dom_n))  # the launches of the timed region only
+    lib.ss_profile_read(ssa._native.PROF_MINHASH_HOP, byref(dom_ms), byref(dom_n))  # the launches of the timed region only
     lib.ss_profile_enable(0)
     if a.api == 'build_query':
         for _ in range(5):

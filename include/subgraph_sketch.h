@@ -193,23 +193,8 @@ int ss_spmm_csr(const int64_t *rowptr, const int32_t *col, const float *val, int
 int ss_pack_minhash(const int64_t *in, uint32_t *out, int64_t count, void *stream);
 int ss_unpack_minhash(const uint32_t *in, int64_t *out, int64_t count, void *stream);
 
-/* Live launch-duration measurement of the dominant kernel (the MinHash table hop inside ss_propagate): while
- * enabled, every such launch is bracketed by HIP events on its own stream.  ss_profile_read synchronises those
- * events, returns their mean duration (ms) and count through host pointers, and clears the list. */
-int ss_profile_enable(int32_t on);
-int ss_profile_read(float *mean_ms_out, int32_t *launches_out);
-
-/* Launch-duration probe for bench.py: records HIP events around `reps` back-to-back launches of the
- * same ss_propagate / ss_pair_features call ON `stream` and returns the mean milliseconds per launch in
- * *ms_out (host pointer).  Synchronises the stream. */
-int ss_time_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
-                      const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
-                      float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream,
-                      int32_t reps, float *ms_out);
-int ss_time_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
-                          const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
-                          const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
-                          float *out, void *stream, int32_t reps, float *ms_out);
+/* Measurement-only entry points (launch-duration probes used by bench.py and tools/) are declared in
+ * subgraph_sketch_debug.h; they are not part of the drop-in boundary. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,49 @@
+/*
+ * subgraph_sketch_debug.h -- measurement-only entry points of libsubgraph_sketch.so.
+ *
+ * NOT part of the drop-in boundary (include/subgraph_sketch.h): nothing here replaces reference code.  bench.py and the
+ * probes under tools/ use these to time launches with HIP events recorded on the very stream a kernel is launched on
+ * (torch.cuda.Event only sees torch's current stream).  Implemented in csrc/ss_debug.hip; the event list is guarded by a
+ * mutex and capped (SS_PROFILE_MAX_EVENTS launches; later launches are not recorded until ss_profile_read drains it).
+ */
+#ifndef SUBGRAPH_SKETCH_DEBUG_H
+#define SUBGRAPH_SKETCH_DEBUG_H
+
+#include "subgraph_sketch.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_PROFILE_MAX_EVENTS 65536
+
+/* Live launch-duration measurement: while a kernel family's bit is enabled, every launch of it -- from any thread, on
+ * any stream -- is bracketed by HIP events recorded on its own stream.  ss_profile_read(tag) synchronises the events of
+ * that family, returns their mean duration (ms) and count through host pointers, and removes them from the list. */
+#define SS_PROF_MINHASH_HOP 0     /* ss::propagate_kernel<128,256>, MinHash table hop (the dominant kernel of a build)   */
+#define SS_PROF_HLL_HOP 1         /* ss::hll_propagate_row16_kernel, HLL table hop + cardinalities                       */
+#define SS_PROF_FIRST_HOP_MH 2    /* ss::first_hop_kernel<..., true, false>                                              */
+#define SS_PROF_FIRST_HOP_HLL 3   /* ss::hll_first_hop_kernel                                                            */
+#define SS_PROF_PAIRS 4           /* ss::pair_features_kernel                                                            */
+#define SS_PROF_CSR 5             /* all launches of one ss_csr_build                                                    */
+#define SS_PROF_HUB 6             /* hub / mega-row passes (propagate_hub_kernel, first_hop_hub_kernel)                  */
+#define SS_PROF_TAGS 7
+int ss_profile_enable(uint32_t tag_mask);   /* bit t enables family t; 0 disables everything */
+int ss_profile_read(int32_t tag, float *mean_ms_out, int32_t *launches_out);
+
+/* Launch-duration probe for bench.py: records HIP events around `reps` back-to-back launches of the
+ * same ss_propagate / ss_pair_features call ON `stream` and returns the mean milliseconds per launch in
+ * *ms_out (host pointer).  Synchronises the stream. */
+int ss_time_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
+                      const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
+                      float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream,
+                      int32_t reps, float *ms_out);
+int ss_time_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
+                          const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
+                          const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
+                          float *out, void *stream, int32_t reps, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUBGRAPH_SKETCH_DEBUG_H */

@@ -31,11 +31,12 @@ class CsrGraphStruct(ctypes.Structure):
                 ('mega_scratch', c_void_p), ('row_begin', c_int64), ('row_end', c_int64)]
 
 
-ABI_VERSION = 110  # ss_version() of the library this module's struct mirrors and signatures describe
+ABI_VERSION = 120  # ss_version() of the library this module's struct mirrors and signatures describe
+PROF_MINHASH_HOP, PROF_HLL_HOP, PROF_FIRST_HOP_MH, PROF_FIRST_HOP_HLL, PROF_PAIRS, PROF_CSR, PROF_HUB = range(7)  # SS_PROF_* tags
 MEGA_SLICE, MEGA_SLOT_BYTES = 4096, 1280  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
 
 
-# name -> (restype, argtypes); must list every symbol declared in include/subgraph_sketch.h
+# name -> (restype, argtypes); must list every symbol declared in include/subgraph_sketch.h and include/subgraph_sketch_debug.h
 SIGNATURES = {
     'ss_version': (c_int32, []),
     'ss_error_string': (c_char_p, [c_int32]),
@@ -61,8 +62,8 @@ SIGNATURES = {
     'ss_spmm_csr': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     'ss_pack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_unpack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
-    'ss_profile_enable': (c_int32, [c_int32]),
-    'ss_profile_read': (c_int32, [POINTER(c_float), POINTER(c_int32)]),
+    'ss_profile_enable': (c_int32, [c_uint32]),
+    'ss_profile_read': (c_int32, [c_int32, POINTER(c_float), POINTER(c_int32)]),
     'ss_time_propagate': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p,
                                     c_void_p, c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int32,
                                     POINTER(c_float)]),

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "subgraph_sketch.h"
+#include "subgraph_sketch_debug.h"
 
 #define SS_LAUNCH_CHECK()                                        \
     do {                                                         \
@@ -208,8 +209,17 @@ constexpr int kMegaSlot = SS_MEGA_SLOT_BYTES, kMegaHllOffset = 1024;
 
 // Cross-workgroup hand-off of the mega-row partials WITHOUT cache-wide fences: the 8 XCD L2s are not coherent with each
 // other, and a device-scope release / acquire fence (__threadfence) writes back and invalidates a whole L2 -- measured
-// 1.6 ms for 135 slices, slower than not slicing at all.  Device-scope relaxed atomics instead go to the coherence point
-// access by access; the ticket that publishes them is ordered behind them by a workgroup-scope fence (a wait, no flush).
+// 1.6 ms for 135 slices, slower than not slicing at all.  The protocol instead is the write-through one of
+// MI355X_MICROARCH.md "Inter-workgroup visibility" / cdna_hip_programming.md Guideline 16 (R1):
+//   producer  slot words leave as agent-scope relaxed atomic stores (global_store ... sc1: written through the L2, access by
+//             access) -> EVERY storing wave drains them (publish_drain: s_waitcnt vmcnt(0); gfx9 counts stores in vmcnt, and
+//             a store is only counted down once the memory side has acknowledged it) -> __syncthreads() -> one lane takes
+//             the row's ticket with an agent-scope atomic add.
+//   consumer  the workgroup that draws the last ticket waits for the atomic's return value (a data dependency), passes a
+//             barrier, and reads every slot with agent-scope relaxed atomic loads (global_load ... sc1: L1 bypassed).
+// A workgroup-scope fence in the producer is NOT enough (round-1 bug): on gfx950 it emits no s_waitcnt, so the ticket could
+// reach the memory side before the slot stores and the last finisher combine a stale slot.  The ISA of both hub kernels
+// (profiles/round2_handoff_isa.txt) shows `s_waitcnt vmcnt(0)` between the sc1 stores and the ticket's global_atomic_add.
 __device__ __forceinline__ void coherent_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t coherent_load(const uint32_t *p)
 {
@@ -225,8 +235,13 @@ __device__ __forceinline__ u32x4 coherent_load4(const uint8_t *p)
     const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
     return u32x4{coherent_load(q), coherent_load(q + 1), coherent_load(q + 2), coherent_load(q + 3)};
 }
-// all stores of this workgroup have completed (been acknowledged) before anything that follows the next barrier
-__device__ __forceinline__ void workgroup_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// every vector-memory operation this wave has issued (the sc1 slot stores in particular) has been acknowledged by the
+// memory side.  Inline asm, placed AFTER the stores: the compiler can neither drop nor move it (a builtin wait can be
+// elided when its scoreboard believes nothing is outstanding -- Guideline 16 pitfall 12).
+__device__ __forceinline__ void publish_drain() { asm volatile("s_waitcnt vmcnt(0) ; SS_HANDOFF drain before ticket" ::: "memory"); }
+// the ticket of a mega row: agent-scope RMW executed at the coherence point; returns the number of slices that arrived before
+__device__ __forceinline__ int take_ticket(int32_t *counter) { return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void reset_ticket(int32_t *counter) { __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct GraphArgs {  // device-side view of ss_csr_graph
     const int64_t *rowptr;
@@ -253,6 +268,17 @@ inline GraphArgs to_args(const ss_csr_graph &g)
                      mega ? const_cast<int32_t *>(g.mega_rows) : nullptr, mega ? g.mega_count : nullptr,
                      mega ? static_cast<uint8_t *>(g.mega_scratch) : nullptr, all ? 0 : g.row_begin, all ? g.num_nodes : g.row_end};
 }
+
+// optional HIP-event bracket around a launch (ss_debug.hip; a no-op unless ss_profile_enable selected `tag`)
+struct ProfileSpan {
+    hipEvent_t start = nullptr, stop = nullptr;
+    hipStream_t stream;
+    int tag;
+    ProfileSpan(hipStream_t s, int tag);
+    ~ProfileSpan();
+    ProfileSpan(const ProfileSpan &) = delete;
+    ProfileSpan &operator=(const ProfileSpan &) = delete;
+};
 
 inline bool row_range_ok(const ss_csr_graph &g)
 {

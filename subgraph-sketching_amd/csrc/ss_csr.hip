@@ -533,6 +533,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
         return SS_OK;
     }
     const Workspace w = carve(p, E, workspace);
+    ProfileSpan span(stream, SS_PROF_CSR);  // all launches of this build
     unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
 
     // ---- pass 1 ----

@@ -280,12 +280,12 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
                 }
                 if (DO_HLL) coherent_store(reinterpret_cast<uint32_t *>(mine + kMegaHllOffset) + lane, pack_hll_quad(hll_row, lane));
             }
-            workgroup_release();  // see ss_common.hpp: no cache-wide fence
+            publish_drain();  // every wave: the slot stores are acknowledged before the barrier that precedes the ticket
             __syncthreads();
             if (threadIdx.x == 0) {
-                const int prev = atomicAdd(&g.mega_rows[4 * m + 3], 1);
+                const int prev = take_ticket(&g.mega_rows[4 * m + 3]);
                 s_last = prev == e.z - 1;
-                if (s_last) g.mega_rows[4 * m + 3] = 0;
+                if (s_last) reset_ticket(&g.mega_rows[4 * m + 3]);
             }
             __syncthreads();
             if (s_last) {
@@ -324,8 +324,11 @@ int launch_first_hop_v(const GraphArgs &g, const uint64_t *a, const uint64_t *b,
 {
     const int64_t blocks = (g.rows() + 3) / 4;
     const bool hubs = g.hub_rows && g.hub_count;
-    hipLaunchKernelGGL((first_hop_kernel<PPL, DO_MH, DO_HLL>), dim3((unsigned)blocks), dim3(256), 0, s, g, a, b, mh_out, p, hll_out,
-                       cards_out, cards_stride, prm, hubs);
+    {
+        ProfileSpan span(s, DO_MH && !DO_HLL ? SS_PROF_FIRST_HOP_MH : SS_PROF_TAGS);
+        hipLaunchKernelGGL((first_hop_kernel<PPL, DO_MH, DO_HLL>), dim3((unsigned)blocks), dim3(256), 0, s, g, a, b, mh_out, p, hll_out,
+                           cards_out, cards_stride, prm, hubs);
+    }
     SS_LAUNCH_CHECK();
     if (hubs) {
         hipLaunchKernelGGL((first_hop_hub_kernel<PPL, DO_MH, DO_HLL>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p,
@@ -343,19 +346,28 @@ int launch_first_hop(const GraphArgs &g, const uint64_t *a, const uint64_t *b, u
         // both sketches: the latency-optimised HLL kernel + the MinHash kernel beat the combined kernel (37 + 134 us vs
         // 184 us on the bench graph); one hub pass serves both
         const bool hubs = g.hub_rows && g.hub_count;
-        hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows))), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
-                           prm, hubs);
+        {
+            ProfileSpan span(s, SS_PROF_FIRST_HOP_HLL);
+            hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows))), dim3(256), 0, s, g, p,
+                               hll_out, cards_out, cards_stride, prm, hubs);
+        }
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL((first_hop_kernel<PPL, true, false>), dim3((unsigned)((g.rows() + 3) / 4)), dim3(256), 0, s, g, a, b, mh_out, p,
-                           (uint8_t *)nullptr, (float *)nullptr, (int64_t)0, prm, hubs);
+        {
+            ProfileSpan span(s, SS_PROF_FIRST_HOP_MH);
+            hipLaunchKernelGGL((first_hop_kernel<PPL, true, false>), dim3((unsigned)((g.rows() + 3) / 4)), dim3(256), 0, s, g, a, b, mh_out,
+                               p, (uint8_t *)nullptr, (float *)nullptr, (int64_t)0, prm, hubs);
+        }
         SS_LAUNCH_CHECK();
         return launch_first_hop_hub_only(g, a, b, PPL * kWave, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
     }
     if (mh_out) return launch_first_hop_v<PPL, true, false>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
     // HLL alone: 16-lane-per-row kernel for the regular rows, the cooperative hub kernel for the rest
     const bool hubs = g.hub_rows && g.hub_count;
-    hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows))), dim3(256), 0, s, g, p, hll_out, cards_out, cards_stride,
-                       prm, hubs);
+    {
+        ProfileSpan span(s, SS_PROF_FIRST_HOP_HLL);
+        hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows))), dim3(256), 0, s, g, p,
+                           hll_out, cards_out, cards_stride, prm, hubs);
+    }
     SS_LAUNCH_CHECK();
     if (hubs) {
         hipLaunchKernelGGL((first_hop_hub_kernel<PPL, false, true>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p,
@@ -386,6 +398,7 @@ int launch_first_hop_hub_only(const GraphArgs &g, const uint64_t *a, const uint6
                               float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
 {
     if (!g.hub_rows || !g.hub_count) return SS_OK;
+    ProfileSpan span(stream, SS_PROF_HUB);
     switch (P / kWave) {
         case 1: return hub_only<1>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, stream);
         case 2: return hub_only<2>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, stream);

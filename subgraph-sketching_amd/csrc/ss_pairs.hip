@@ -299,8 +299,11 @@ int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &t
     int64_t blocks = (B + 2 * pairs_per_block - 1) / (2 * pairs_per_block);
     if (blocks > kPairGrid) blocks = kPairGrid;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((pair_features_kernel<H, TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, links, B, N, tabs, P, M,
-                       cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees);
+    {
+        ProfileSpan span(stream, SS_PROF_PAIRS);
+        hipLaunchKernelGGL((pair_features_kernel<H, TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, links, B, N, tabs, P, M,
+                           cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees);
+    }
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -14,7 +14,6 @@
 // dependent 1 KiB loads on one wavefront (power-law graphs: ogbl-ppa, ogbl-citation2).  The row kernel
 // skips them and propagate_hub_kernel gives each of them a whole 16-wave workgroup: 32 MinHash / 64 HLL
 // neighbours per step, partials combined through LDS.
-#include <vector>
 #include "ss_walks.hpp"
 
 namespace ss {
@@ -242,12 +241,12 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
                 if (mh_out && lane < CM) coherent_store4(mine + 16 * lane, mh_acc);
                 if (hll_out && lane >= 32 && lane < 32 + CH) coherent_store4(mine + kMegaHllOffset + 16 * (lane - 32), hll_acc);
             }
-            workgroup_release();  // the partial row has reached the coherence point before the ticket is taken
+            publish_drain();  // every wave: the slot stores are acknowledged before the barrier that precedes the ticket
             __syncthreads();
             if (threadIdx.x == 0) {
-                const int prev = atomicAdd(&g.mega_rows[4 * m + 3], 1);
+                const int prev = take_ticket(&g.mega_rows[4 * m + 3]);
                 s_last = prev == e.z - 1;
-                if (s_last) g.mega_rows[4 * m + 3] = 0;  // every slice has arrived: ready for the next hop
+                if (s_last) reset_ticket(&g.mega_rows[4 * m + 3]);  // every slice has arrived: ready for the next hop
             }
             __syncthreads();
             if (s_last) {
@@ -267,27 +266,6 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
     }
 }
 
-// ---- live timing of the MinHash table hop (ss_profile_enable / ss_profile_read) --------------------------------
-static bool g_profile_on = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_profile_events;
-
-struct ProfileSpan {
-    hipEvent_t start = nullptr, stop = nullptr;
-    hipStream_t stream;
-    explicit ProfileSpan(hipStream_t s, bool wanted = true) : stream(s)
-    {
-        if (!g_profile_on || !wanted) return;
-        if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) { start = nullptr; return; }
-        (void)hipEventRecord(start, stream);
-    }
-    ~ProfileSpan()
-    {
-        if (!start) return;
-        (void)hipEventRecord(stop, stream);
-        g_profile_events.emplace_back(start, stop);
-    }
-};
-
 template <int TP, int TM>
 int launch_propagate(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, int P, const uint8_t *hll_in, uint8_t *hll_out, int M,
                      float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
@@ -296,7 +274,7 @@ int launch_propagate(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out
     const int64_t blocks = (g.rows() + rows_per_block - 1) / rows_per_block;
     const bool hubs = TP == 128 && TM == 256 && g.hub_rows && g.hub_count;
     {
-        ProfileSpan span(stream, mh_out && !hll_out && TP == 128);  // MinHash table hop
+        ProfileSpan span(stream, mh_out && !hll_out && TP == 128 ? SS_PROF_MINHASH_HOP : SS_PROF_TAGS);  // MinHash table hop
         hipLaunchKernelGGL((propagate_kernel<TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, g, mh_in, mh_out, P, hll_in, hll_out,
                            M, cards_out, cards_stride, prm, hubs);
     }
@@ -313,6 +291,7 @@ int launch_propagate_hub_only(const GraphArgs &g, const uint32_t *mh_in, uint32_
                               float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
 {
     if (!g.hub_rows || !g.hub_count) return SS_OK;
+    ProfileSpan span(stream, SS_PROF_HUB);
     hipLaunchKernelGGL(propagate_hub_kernel, dim3(kHubGrid), dim3(kHubThreads), 0, stream, g, mh_in, mh_out, hll_in, hll_out, cards_out,
                        cards_stride, prm);
     SS_LAUNCH_CHECK();
@@ -349,8 +328,11 @@ extern "C" int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, ui
     const int64_t R = g.rows();
     if (!mh_out && M == 256) {  // HLL alone: 4 destinations per wavefront
         const bool hubs = g.hub_rows && g.hub_count;
-        hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, g, hll_in, hll_out,
-                           cards_out, cards_stride, p0, hubs);
+        {
+            ProfileSpan span((hipStream_t)stream, SS_PROF_HLL_HOP);
+            hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, g, hll_in,
+                               hll_out, cards_out, cards_stride, p0, hubs);
+        }
         SS_LAUNCH_CHECK();
         return launch_propagate_hub_only(g, nullptr, nullptr, hll_in, hll_out, cards_out, cards_stride, p0, (hipStream_t)stream);
     }
@@ -359,11 +341,14 @@ extern "C" int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, ui
         // graph): the HLL kernel keeps 4 destinations in flight per wavefront, the MinHash kernel one; a single hub pass
         // serves both
         const bool hubs = g.hub_rows && g.hub_count;
-        hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, g, hll_in, hll_out,
-                           cards_out, cards_stride, p0, hubs);
+        {
+            ProfileSpan span((hipStream_t)stream, SS_PROF_HLL_HOP);
+            hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, g, hll_in,
+                               hll_out, cards_out, cards_stride, p0, hubs);
+        }
         SS_LAUNCH_CHECK();
         {
-            ProfileSpan span((hipStream_t)stream);
+            ProfileSpan span((hipStream_t)stream, SS_PROF_MINHASH_HOP);
             hipLaunchKernelGGL((propagate_kernel<128, 256>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, mh_in,
                                mh_out, 128, (const uint8_t *)nullptr, (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, p0, hubs);
         }
@@ -375,30 +360,4 @@ extern "C" int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, ui
     if (fast)
         return launch_propagate<128, 256>(g, mh_in, mh_out, 128, hll_in, hll_out, 256, cards_out, cards_stride, p0, (hipStream_t)stream);
     return launch_propagate<0, 0>(g, mh_in, mh_out, P, hll_in, hll_out, M, cards_out, cards_stride, p0, (hipStream_t)stream);
-}
-
-extern "C" int ss_profile_enable(int32_t on)
-{
-    ss::g_profile_on = on != 0;
-    return SS_OK;
-}
-
-extern "C" int ss_profile_read(float *mean_ms_out, int32_t *launches_out)
-{
-    if (!mean_ms_out || !launches_out) return SS_ERR_INVALID_ARG;
-    double total = 0.0;
-    int n = 0;
-    for (auto &ev : ss::g_profile_events) {
-        float ms = 0.0f;
-        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
-            total += ms;
-            ++n;
-        }
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
-    }
-    ss::g_profile_events.clear();
-    *mean_ms_out = n ? (float)(total / n) : 0.0f;
-    *launches_out = n;
-    return SS_OK;
 }

@@ -1,5 +1,5 @@
-"""The C-ABI library loads on a GPU-less host and exports every symbol include/subgraph_sketch.h declares
-(no compute calls here)."""
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/subgraph_sketch.h (the drop-in boundary)
+and include/subgraph_sketch_debug.h (measurement-only probes) declare (no compute calls here)."""
 import ctypes
 import os
 import re
@@ -9,14 +9,18 @@ import pytest
 from conftest import REPO
 
 
-def _declared_symbols():
-    text = open(os.path.join(REPO, 'include', 'subgraph_sketch.h')).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(ss_[a-z0-9_]+)\s*\(', text)))
+def _declared_symbols(headers=('subgraph_sketch.h', 'subgraph_sketch_debug.h')):
+    names = set()
+    for header in headers:
+        text = open(os.path.join(REPO, 'include', header)).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        names |= set(re.findall(r'\b(ss_[a-z0-9_]+)\s*\(', text))
+    return sorted(names)
 
 
 def test_header_declares_the_expected_boundary():
-    names = _declared_symbols()
+    names = _declared_symbols(('subgraph_sketch.h',))
+    assert not [n for n in names if n.startswith(('ss_time_', 'ss_profile_'))], 'probes belong in subgraph_sketch_debug.h'
     for needed in ('ss_minhash_init', 'ss_hll_init', 'ss_csr_build', 'ss_propagate', 'ss_hll_count', 'ss_pair_features',
                    'ss_pack_minhash', 'ss_unpack_minhash', 'ss_estimate_bias', 'ss_version', 'ss_error_string'):
         assert needed in names
@@ -39,10 +43,21 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_strings():
     import subgraph_sketching_amd as ssa
     lib = ssa._native.lib()
-    assert lib.ss_version() == 110
+    assert lib.ss_version() == 120 == ssa._native.ABI_VERSION
     assert lib.ss_error_string(0) == b'ok'
     assert b'invalid' in lib.ss_error_string(-1)
     assert lib.ss_csr_workspace_bytes(1000, 5000) >= 8 * 1001
+
+
+def test_profile_probe_bookkeeping_without_a_gpu():
+    """the tagged span list: nothing recorded -> zero launches; bad tags are argument errors"""
+    from ctypes import byref, c_float, c_int32
+    import subgraph_sketching_amd as ssa
+    lib = ssa._native.lib()
+    ms, n = c_float(-1.0), c_int32(-1)
+    assert lib.ss_profile_enable(0) == 0
+    assert lib.ss_profile_read(ssa._native.PROF_MINHASH_HOP, byref(ms), byref(n)) == 0 and n.value == 0 and ms.value == 0.0
+    assert lib.ss_profile_read(99, byref(ms), byref(n)) == -1
 
 
 def test_argument_errors_are_reported_without_a_gpu():
