@@ -150,6 +150,14 @@ def hll_count(regs, params, return_branch=False):
     return (out, br) if return_branch else out
 
 
+def estimate_bias(e, params, refine=False):
+    """hashing.py:197-204 (_estimate_bias) / :206-210 (_refine_hll_count_estimate, refine=True) for raw estimates e [n]"""
+    e = np.ascontiguousarray(e, dtype=np.float32)
+    out = np.empty_like(e)
+    lib().so_estimate_bias(_p(e), c_int64(e.size), ctypes.byref(params.struct), c_int32(int(refine)), _p(out))
+    return out
+
+
 def build_hash_tables(num_nodes, edge_index, max_hops, num_perm, params):
     """hashing.py:139-165.  returns ({k: {'hll': uint8 [N,m], 'minhash': uint32 [N,P]}}, cards fp32 [N, max_hops])"""
     ei = add_self_loops(edge_index)

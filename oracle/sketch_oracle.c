@@ -150,6 +150,16 @@ static float estimate_bias(const so_hll_params *prm, float e)
     return s / (float)nb;
 }
 
+/* hashing.py:197-204 (refine == 0: the mean bias itself) and :206-210 (refine != 0: e <= 5m ? e - bias : e) on their own */
+void so_estimate_bias(const float *e, int64_t n, const so_hll_params *prm, int32_t refine, float *out)
+{
+    const float five_m = 5.0f * (float)((int64_t)1 << prm->p);
+    for (int64_t i = 0; i < n; ++i) {
+        const float b = estimate_bias(prm, e[i]);
+        out[i] = refine ? (e[i] <= five_m ? e[i] - b : e[i]) : b;
+    }
+}
+
 /* hashing.py:212-232 hll_count for one register row (+ :206-210 _refine_hll_count_estimate).
  * branch (optional out): 0 = linear counting, 1 = raw estimate with bias correction (e <= 5m),
  * 2 = raw estimate unchanged (e > 5m). */

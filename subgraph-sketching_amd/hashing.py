@@ -216,10 +216,23 @@ SketchTable = dict
 PACKED_FORMAT = 'subgraph-sketch-packed-v1'
 
 
-def save_sketches(path, table, cards):
+def _stamp_tables(cards, tables_id):
+    """remember which HLL++ tables produced these cardinalities (python attribute: survives as long as the tensor object)"""
+    try:
+        cards._ss_tables = tables_id
+    except Exception:  # pragma: no cover
+        pass
+    return cards
+
+
+def save_sketches(path, table, cards, hll_tables_id=None):
     """packed on-disk cache: uint32 MinHash + uint8 HLL per hop (768 B per node and hop at the defaults instead of the
     1 280 B of the reference's int64/int8 `torch.save(hashes)` cache, datasets/elph.py:204).  Plain tensors and
-    scalars only, so `torch.load(..., weights_only=True)` reads it."""
+    scalars only, so `torch.load(..., weights_only=True)` reads it.  The identity of the HLL++ tables that produced
+    `cards` (hll_tables.table_id; taken from the stamp build_hash_tables leaves on `cards` unless given) is stored too:
+    load_sketches / get_subgraph_features refuse to combine it with another table."""
+    if hll_tables_id is None:
+        hll_tables_id = getattr(cards, '_ss_tables', None)
     hops = {}
     for k, entry in table.items():
         if isinstance(entry, HopSketch):
@@ -228,13 +241,15 @@ def save_sketches(path, table, cards):
             device = _compute_device(entry['minhash'], entry['hll'])
             mh, hll = _packed_minhash_of(entry['minhash'], device), _packed_hll_of(entry['hll'], device)
         hops[int(k)] = {'minhash_u32': mh.cpu(), 'hll_u8': hll.cpu()}
-    torch.save({'format': PACKED_FORMAT, 'hops': hops, 'cards': cards.cpu()}, path)
+    torch.save({'format': PACKED_FORMAT, 'hops': hops, 'cards': cards.cpu(), 'hll_tables': hll_tables_id or 'unknown'}, path)
 
 
-def load_sketches(path, device=None):
+def load_sketches(path, device=None, expect=None):
     """read a packed cache (save_sketches) or the reference's own cache files back into (SketchTable, cards).
     The reference's format ({k: {'hll': int8, 'minhash': int64}}) is returned as loaded -- get_subgraph_features
-    accepts it directly; pass the cards file separately in that case."""
+    accepts it directly; pass the cards file separately in that case.
+    expect: an ElphHashes (or a table id string); a packed cache whose cardinalities were produced with OTHER HLL++ tables
+    raises ValueError instead of being mixed with this engine's estimates."""
     blob = torch.load(path, map_location='cpu', weights_only=True)
     if not (isinstance(blob, dict) and blob.get('format') == PACKED_FORMAT):
         return blob, None
@@ -242,7 +257,12 @@ def load_sketches(path, device=None):
     table = SketchTable()
     for k, entry in blob['hops'].items():
         table[int(k)] = HopSketch(entry['minhash_u32'].to(device), entry['hll_u8'].to(device), device)
-    return table, blob['cards'].to(device)
+    cached_id = blob.get('hll_tables', 'unknown')
+    want = expect.tables_id if isinstance(expect, ElphHashes) else expect
+    if want is not None and cached_id != 'unknown' and cached_id != want:
+        raise ValueError(f'{path} holds cardinalities made with HLL++ tables {cached_id}, this engine uses {want}')
+    cards = blob['cards'].to(device)
+    return table, (_stamp_tables(cards, cached_id) if cached_id != 'unknown' else cards)
 
 
 def pack_minhash(x, device=None):
@@ -426,7 +446,9 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
     n_self_dev = flags[0:1]
     hub_count = flags32[2:3]
     mega_count = flags32[4:6]
-    err = flags32[3:4] if check else _error_flag(device)  # strict mode reads its own flag together with the counters below
+    # strict mode reads its own flag together with the counters below; a non-strict build passes NO flag (a shared one
+    # would stay set and make the next strict call raise for valid inputs)
+    err = flags32[3:4] if check else None
     if check:
         err.zero_()
     hub_rows = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=device)
@@ -628,6 +650,7 @@ class ElphHashes(object):
         state = dict(self.__dict__)
         state['_dev_params'], state['_dev_perms'] = {}, {}
         state['_csr_cache'] = None
+        state.pop('_tables_id', None)
         state['minhash_prop'], state['hll_prop'] = None, None
         return state
 
@@ -638,6 +661,15 @@ class ElphHashes(object):
         self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m)
 
     # ---- host-side helpers -------------------------------------------------------------------------
+    @property
+    def tables_id(self):
+        """identity of the HLL++ tables in use (hll_tables.table_id), recomputed if `hll_tables` is replaced"""
+        cached = self.__dict__.get('_tables_id')
+        if cached is None or cached[0] is not self.hll_tables:
+            cached = (self.hll_tables, hll_tables.table_id(self.hll_tables))
+            self.__dict__['_tables_id'] = cached
+        return cached[1]
+
     def _params(self, device):
         key = str(device)
         if key not in self._dev_params:
@@ -785,7 +817,7 @@ class ElphHashes(object):
             cards = cards[:num_nodes]
         for k in range(1, h + 1):
             table[k] = HopSketch(mh[k - 1][:num_nodes], hll[k - 1][:num_nodes], home)
-        return table, (cards if home == device else cards.to(home))
+        return table, _stamp_tables(cards if home == device else cards.to(home), self.tables_id)
 
     def _first_hop(self, csr, device, mh_out, hll_out, cards, params, rows=None):
         """fused hop-0 + hop-1 (ss_first_hop) for either or both sketches"""
@@ -827,6 +859,10 @@ class ElphHashes(object):
         if cards is None:
             cd = torch.zeros((N, h), dtype=torch.float32, device=device)
         else:
+            made_with = getattr(cards, '_ss_tables', None)
+            if made_with is not None and made_with != self.tables_id:
+                raise ValueError(f'cards were estimated with HLL++ tables {made_with}, this engine uses {self.tables_id}: '
+                                 f'a feature row would mix two bias tables (rebuild the cache or load the same tables)')
             # ELPH keeps `cards` on the CPU and the reference re-uploads it on every call (hashing.py:274): keep a device
             # twin on the tensor, invalidated by in-place edits, so repeated eval batches do not pay the copy again
             tag = getattr(cards, '_ss_cards', None)
@@ -845,7 +881,7 @@ class ElphHashes(object):
         mh_ptrs = (c_void_p * h)(*[t.data_ptr() for t in mh])
         hll_ptrs = (c_void_p * h)(*[t.data_ptr() for t in hll])
         flags = (_native.SS_FLAG_USE_ZERO_ONE if self.use_zero_one else 0) | (_native.SS_FLAG_FLOOR_SF if self.floor_sf else 0)
-        err = _error_flag(device)
+        err = _error_flag(device) if self.strict_bounds else None  # non-strict launches never touch the shared flag
         if degrees is not None:
             dg = degrees.to(device=device, dtype=torch.float32).contiguous()
             if dg.dim() != 1 or dg.numel() != N:

@@ -186,3 +186,57 @@ def test_abi_constants_match_the_header():
     fields = re.search(r'typedef struct ss_csr_graph \{(.*?)\} ss_csr_graph;', text, re.S).group(1)
     names = re.findall(r'(\w+);', re.sub(r'/\*.*?\*/', '', fields, flags=re.S))
     assert names == [f[0] for f in _native.CsrGraphStruct._fields_]   # the ctypes mirror lists the same fields in the same order
+
+
+def test_regenerated_tables_warn_and_are_identified(ssa, caplog, monkeypatch):
+    """the silent fall-back to simulated HLL++ tables now logs a warning (once per precision), and every table
+    has an identity (provenance + digest of the numbers) that travels with the cardinalities it produced"""
+    import logging
+    ht = ssa.hll_tables
+    monkeypatch.setattr(ht, '_warned', set())
+    monkeypatch.setattr(ht, 'EXPORTED', '/nonexistent/hllpp_tables_datasketch.npz')
+    try:
+        import datasketch  # noqa: F401
+        pytest.skip('datasketch is importable here: the fall-back is not taken')
+    except ImportError:
+        pass
+    with caplog.at_level(logging.WARNING, logger=ht.logger.name):
+        t = ht.load(8)
+        ht.load(8)
+    assert t.provenance == 'regenerated'
+    assert sum('REGENERATED' in r.getMessage() for r in caplog.records) == 1
+    tid = ht.table_id(t)
+    assert tid.startswith('regenerated:') and tid == ht.table_id(ht.load(8, prefer='regenerated'))
+    other = t._replace(bias=t.bias + 1e-3)
+    assert ht.table_id(other) != tid and ht.table_id(t._replace(provenance='datasketch')) != tid
+    eh = ssa.ElphHashes(_args())
+    assert eh.tables_id == tid
+    eh.hll_tables = other
+    assert eh.tables_id == ht.table_id(other)  # recomputed when the tables are replaced
+
+
+def test_exported_datasketch_tables_are_preferred_over_regenerated(ssa, tmp_path, monkeypatch):
+    """data/hllpp_tables_datasketch.npz (written by tools/export_datasketch_fixture.py where datasketch is installed) is
+    used when the package itself is absent; the exporter's file format round-trips through hll_tables.load"""
+    import importlib.util
+    from conftest import REPO
+    import os
+    ht = ssa.hll_tables
+    try:
+        import datasketch  # noqa: F401
+        pytest.skip('datasketch is importable here')
+    except ImportError:
+        pass
+    spec = importlib.util.spec_from_file_location('export_ds', os.path.join(REPO, 'tools', 'export_datasketch_fixture.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    fake = {p: ht.load(p, prefer='regenerated')._replace(alpha=0.5 + p / 100.0) for p in (4, 8)}
+    path = tmp_path / 'hllpp_tables_datasketch.npz'
+    tool.write_tables(str(path), fake)
+    monkeypatch.setattr(ht, 'EXPORTED', str(path))
+    t = ht.load(8)
+    assert t.provenance == 'datasketch-export' and t.alpha == 0.58 and np.array_equal(t.bias, fake[8].bias)
+    assert ht.load(6).provenance == 'regenerated'  # a precision the export does not hold
+    with pytest.raises(ImportError):
+        monkeypatch.setattr(ht, 'EXPORTED', '/nonexistent.npz')
+        ht.load(8, prefer='datasketch')

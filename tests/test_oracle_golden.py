@@ -251,3 +251,48 @@ def test_sign_feature_propagation_restatement():
     dinv = np.where(deg > 0, deg ** -0.5, 0.0)
     want = (dinv[:, None] * A * dinv[None, :]) @ x.astype(np.float64)
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+
+
+def test_estimate_bias_entry_point_matches_the_hll_count_branch(regenerated_tables):
+    """so_estimate_bias (the stand-alone _estimate_bias / _refine_hll_count_estimate) against golden G5's values"""
+    prm = oracle_params(regenerated_tables[8])
+    t = regenerated_tables[8]
+    e = np.linspace(float(t.raw_estimate.min()), 1400.0, 200).astype(np.float32)
+    bias = oracle.estimate_bias(e, prm)
+    raw32, bias32 = t.raw_estimate.astype(np.float32), t.bias.astype(np.float32)
+    for x, b in zip(e[::17], bias[::17]):  # independent numpy restatement: stable argsort of fp32 squared distances
+        near = np.argsort((x - raw32) ** 2, kind='stable')[:6]
+        want = np.float32(0)
+        for j in near:
+            want = np.float32(want + bias32[j])
+        assert b == np.float32(want / np.float32(6))
+    refined = oracle.estimate_bias(e, prm, refine=True)
+    small = e <= np.float32(1280.0)
+    assert np.array_equal(refined[small], (e - bias)[small]) and np.array_equal(refined[~small], e[~small])
+
+
+def test_datasketch_tables_fixture():
+    """VERDICT r1 missing #4: real HLL++ tables.  tests/golden/g11_datasketch_tables.npz and
+    subgraph-sketching_amd/data/hllpp_tables_datasketch.npz are produced by tools/export_datasketch_fixture.py on a
+    machine that has `datasketch`; until someone commits them this test SKIPS (loudly) and the bias-corrected branch stays
+    'parity unpinned'.  With them: the shipped export hashes to the recorded digests, hll_tables.load() serves it, and the
+    oracle's bias correction reproduces the float64 known answers computed from datasketch's own numbers."""
+    import os
+    import hashlib
+    from conftest import GOLDEN
+    import subgraph_sketching_amd as ssa
+    path = os.path.join(GOLDEN, 'g11_datasketch_tables.npz')
+    if not (os.path.exists(path) and os.path.exists(ssa.hll_tables.EXPORTED)):
+        pytest.skip('PARITY UNPINNED: no datasketch export committed (run tools/export_datasketch_fixture.py where datasketch '
+                    'is installed and commit its two output files)')
+    g = dict(np.load(path, allow_pickle=False))
+    for p in (4, 6, 8, 12, 16):
+        t = ssa.hll_tables._from_export(p)
+        assert t is not None and t.provenance == 'datasketch-export'
+        assert hashlib.sha256(np.asarray(t.raw_estimate, dtype=np.float64).tobytes()).hexdigest() == str(g[f'sha_raw_p{p}'])
+        assert hashlib.sha256(np.asarray(t.bias, dtype=np.float64).tobytes()).hexdigest() == str(g[f'sha_bias_p{p}'])
+        assert t.alpha == float(g[f'alpha_p{p}']) and t.threshold == float(g[f'threshold_p{p}'])
+        assert ssa.hll_tables.table_id(t) == str(g[f'table_id_p{p}'])
+        prm = oracle_params(t, with_lc=False)
+        got = oracle.estimate_bias(g[f'estimate_p{p}'].astype(np.float32), prm, refine=True)
+        np.testing.assert_allclose(got, g[f'corrected_p{p}'], rtol=2e-6, atol=2e-4 * (1 << p) / 256)
