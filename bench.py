@@ -4,28 +4,41 @@
 metric   : edge-pairs/sec subgraph-feature extraction (build+query)
 workload : configs[1] "ogbl-collab, BUDDY, max_hash_hops=2, batch_size=65536" as a synthetic graph of the same
            shape: N=235 868 nodes, E_und=1 179 052 uniform-random undirected edges
-           (seed 1, both directions -> E_dir=2 358 104), P=128, p=8, h=2; one batch of B=65 536 node pairs per
-           step and per GPU (seed 2+rank).
-step     : one pass of the whole hot path over one batch: ElphHashes.build_hash_tables (CSR build, hop-0
-           sketches, h propagation hops with fused cardinalities) + ElphHashes.get_subgraph_features(B pairs),
-           i.e. what ELPH does per training step (reference runners/train.py:198,204) and what BUDDY does once
-           per edge set.  Nothing is cached between steps.  Inputs (edge_index, links) are resident in HBM.
-N > 1    : one process per GPU (torchrun), sketch table replicated (every rank builds it), edge batches
-           sharded -- each rank owns its own B pairs -- and the per-batch feature rows all-gathered over
-           RCCL (async all_gather_into_tensor on RCCL's stream, overlapped with the next step's build, double-buffered,
-           every gather completed inside the timed region).  Weak scaling.
-roofline : dominant kernel = ss::propagate_kernel (one launch per hop).  achieved = algorithmic bytes per
-           launch ((E'+N)*768 + 4E' + 8(N+1) + 4N, E' = E_dir + N) / mean launch
-           duration measured live in the timed region with HIP events on the launch stream.
-cpu_baseline : the oracle's C port (oracle/sketch_oracle.c, OpenMP on all host cores) timed on ONE full step
-           of the same workload, rank 0 / N=1 only.
+           (seed 1, both directions -> E_dir=2 358 104), P=128, p=8, h=2; one batch of B=65 536 node pairs per step.
+step     : one pass of the whole hot path over one batch: ElphHashes.build_hash_tables (CSR build, hop 1 from node ids,
+           h-1 table hops with fused cardinalities) + ElphHashes.get_subgraph_features(B pairs), i.e. what ELPH does
+           per training step (reference runners/train.py:198,204) and what BUDDY does once per edge set.  Nothing is
+           cached between steps.  Inputs (edge_index, links) are resident in HBM.
+N > 1    : one process per GPU (torchrun), per-batch feature rows all-gathered over RCCL (async, on RCCL's stream,
+           double-buffered, every gather completed inside the timed region).
+           --scaling weak (default): every rank owns its own B pairs AND repeats the whole build (table replicated):
+               the N-GPU rate is ~N x by construction -- `redundant_fraction_of_step` says how much of a rank's step is
+               work every rank repeats;
+           --scaling strong: ONE global batch of B pairs (BASELINE configs[3] / [4] are fixed global batches sharded across
+               8 GPUs), rank r computes its contiguous slice; with --build sharded the destination rows of every hop are
+               split across the ranks too (in-place all-gather per hop and sketch).  value(N) / value(1) = speed-up.
+           --api buddy: one build, then --buddy-links pairs in batches of B (datasets/elph.py:200-208); strong scaling
+               shards every batch.
+roofline : the dominant kernel = ss::propagate_kernel<128,256>, the MinHash table hop.  achieved = algorithmic bytes per
+           launch ((E'+N)*4P + 4E + 8(N+1), subgraph_sketching_amd/roofline.py) / mean launch duration measured live in
+           the timed region with HIP events recorded INSIDE the library on the launch stream (subgraph_sketch_debug.h).
+           `resident` says where the gathered table lives: a table <= 256 MiB sits in the Infinity Cache and the figure
+           is then a fabric rate, not an HBM rate (`unique_hbm_bytes_per_launch` is what HBM itself must deliver).
+           `traffic` is null: PMC counters cannot be read from inside this process; the separately collected rocprofv3
+           figure is quoted under `traffic_profiled` with the file it comes from.
+step_roofline : the WHOLE step against the HBM peak: bytes of the implemented schedule / ms_per_step.
+kernels  : per kernel family, HIP-event launch durations measured on extra steps after the timed region.
+cpu_baseline : the oracle's C port (oracle/sketch_oracle.c, OpenMP on all host cores) timed on full steps of the same
+           workload, rank 0 / N=1 only; `cpu_baseline_reference_style` = the reference's dataflow in stock torch CPU ops.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
 from argparse import Namespace
+from ctypes import byref, c_float, c_int32
 
 import numpy as np
 import torch
@@ -34,60 +47,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # BASELINE.json configs as synthetic shapes.  The default -- and the only one the driver's
-# plain `python bench.py` measures -- is configs[1] (collab).  The others are selectable for profiling.
+# plain `python bench.py` measures -- is configs[1] (collab).  buddy_links = L of the BUDDY precompute.
 CONFIGS = {
-    'collab': dict(n=235868, e_und=1179052, h=2, batch=65536),      # configs[1] / [2]
-    'cora': dict(n=2485, e_und=3550, h=2, batch=1024),              # configs[0] shape (plumbing)
-    'ppa': dict(n=576289, e_und=21231931, h=2, batch=131072),       # configs[3]
-    'citation2': dict(n=2927963, e_und=30387995, h=3, batch=261424),  # configs[4]
+    'collab': dict(n=235868, e_und=1179052, h=2, batch=65536, buddy_links=2_660_000),       # configs[1] / [2]
+    'cora': dict(n=2485, e_und=3550, h=2, batch=1024, buddy_links=20_000),                    # configs[0] shape (plumbing)
+    'ppa': dict(n=576289, e_und=21231931, h=2, batch=131072, buddy_links=57_600_000),         # configs[3]
+    'citation2': dict(n=2927963, e_und=30387995, h=3, batch=261424, buddy_links=356_000_000),  # configs[4]
 }
-N_NODES, E_UND, H, P, HLL_P, BATCH = 235868, 1179052, 2, 128, 8, 65536
-ROW_BYTES = 4 * P + (1 << HLL_P)
-HBM_PEAK_GBS = 8000.0
-GRAPH_KIND, PL_ALPHA = 'uniform', 0.5
+P, HLL_P = 128, 8
 
 
-def synthetic_graph(seed=1):
+def synthetic_graph(n, e_und, kind='uniform', alpha=0.5, seed=1):
     rng = np.random.RandomState(seed)
-    if GRAPH_KIND == 'uniform':
-        e = rng.randint(0, N_NODES, size=(2, E_UND)).astype(np.int64)
+    if kind == 'uniform':
+        e = rng.randint(0, n, size=(2, e_und)).astype(np.int64)
     else:  # power-law endpoint weights w_i ~ (i+1)^-alpha (Chung-Lu style): exercises hub rows
-        w = np.arange(1, N_NODES + 1, dtype=np.float64) ** -PL_ALPHA
+        w = np.arange(1, n + 1, dtype=np.float64) ** -alpha
         cdf = np.cumsum(w / w.sum())
-        e = np.stack([np.searchsorted(cdf, rng.random_sample(E_UND)), rng.randint(0, N_NODES, size=E_UND)]).astype(np.int64)
-        e = np.minimum(e, N_NODES - 1)
+        e = np.stack([np.searchsorted(cdf, rng.random_sample(e_und)), rng.randint(0, n, size=e_und)]).astype(np.int64)
+        e = np.minimum(e, n - 1)
     return np.concatenate([e, e[::-1]], axis=1)
 
 
-def synthetic_links(seed):
-    return np.random.RandomState(seed).randint(0, N_NODES, size=(BATCH, 2)).astype(np.int64)
+def synthetic_links(n, batch, seed):
+    return np.random.RandomState(seed).randint(0, n, size=(batch, 2)).astype(np.int64)
 
 
-class KernelTimer(object):
-    """HIP-event pairs around the engine's launches, on the stream they are launched on"""
-
-    def __init__(self, only=None):
-        self.events = {}
-        self.only = only  # None = time every launch; else only these span names (fewer event packets in the stream)
-
-    def wants(self, name):
-        return self.only is None or name in self.only
-
-    def record(self, name, stream):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(stream)
-        return ev
-
-    def span(self, name, start, end):
-        self.events.setdefault(name, []).append((start, end))
-
-    def mean_ms(self, name):
-        spans = self.events.get(name, [])
-        return sum(a.elapsed_time(b) for a, b in spans) / max(len(spans), 1), len(spans)
-
-
-def cpu_baseline(ei, links):
-    """oracle C port (OpenMP) on one full step; returns the cpu_baseline object"""
+def cpu_baseline(ei, links, n, h, batch):
+    """oracle C port (OpenMP) on full steps; returns the cpu_baseline object and the features of the last step"""
     import subgraph_sketching_amd as ssa
     from oracle import oracle
     t = ssa.hll_tables.load(HLL_P)
@@ -95,50 +82,50 @@ def cpu_baseline(ei, links):
                            lc_table=ssa.hashing.linear_counting_table(1 << t.p).numpy())
     cores = os.cpu_count()
     oracle.lib()
-    reps = 5 if N_NODES > 100000 else 50
+    reps = 5 if n > 100000 else 50
     t_build = t_query = 0.0
     for _ in range(reps):
         t0 = time.perf_counter()
-        rowptr, col = oracle.csr_build(N_NODES, ei)
+        rowptr, col = oracle.csr_build(n, ei)
         n_self = int(ei.max()) + 1
-        mh, hll = oracle.minhash_init(N_NODES, P), oracle.hll_init(N_NODES, HLL_P)
-        tables, cards = {0: {'minhash': mh, 'hll': hll}}, np.zeros((N_NODES, H), dtype=np.float32)
-        for k in range(1, H + 1):
-            mh, hll, c = oracle.propagate_csr(N_NODES, rowptr, col, n_self, mh, hll, prm)
+        mh, hll = oracle.minhash_init(n, P), oracle.hll_init(n, HLL_P)
+        tables, cards = {0: {'minhash': mh, 'hll': hll}}, np.zeros((n, h), dtype=np.float32)
+        for k in range(1, h + 1):
+            mh, hll, c = oracle.propagate_csr(n, rowptr, col, n_self, mh, hll, prm)
             tables[k] = {'minhash': mh, 'hll': hll}
             cards[:, k - 1] = c
         t1 = time.perf_counter()
-        feats = oracle.pair_features(links, tables, cards, H, prm)
+        feats = oracle.pair_features(links, tables, cards, h, prm)
         t2 = time.perf_counter()
         t_build += t1 - t0
         t_query += t2 - t1
-    return {'value': reps * BATCH / (t_build + t_query), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{reps} full steps (build N={N_NODES}, E_dir={2 * E_UND}, h={H} + {BATCH} pairs each); mean '
+    return {'value': reps * batch / (t_build + t_query), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{reps} full steps (build N={n}, E_dir={ei.shape[1]}, h={h} + {batch} pairs each); mean '
                       f'build {t_build / reps:.2f} s, query {t_query / reps:.3f} s; C/OpenMP restatement of the reference, '
                       f'not the torch/PyG code itself'}, feats
 
 
-def cpu_baseline_reference_style(ei, links):
+def cpu_baseline_reference_style(ei, links, n, h, batch):
     """the reference's dataflow in stock torch CPU ops (oracle/torch_refstyle.py): materialised per-edge messages +
     scatter-amax, int64 MinHash, h^2 x 4 row gathers, argsort-based bias lookup.  One full step (all h hops + the query of
-    one batch) is timed."""
+    one batch) is timed.  Calibration against the real (shimmed) reference: profiles/round2_cpu_baseline_calibration.json."""
     import subgraph_sketching_amd as ssa
     from oracle import oracle, torch_refstyle as tr
     t = ssa.hll_tables.load(HLL_P)
     raw, bias = torch.tensor(t.raw_estimate, dtype=torch.float), torch.tensor(t.bias, dtype=torch.float)
     threads = min(16, os.cpu_count())  # measured best on the 256-core GPU host (8: 3.5 s/hop, 16: 2.5, 32: 3.0, 128: 6.0)
     torch.set_num_threads(threads)
-    mh0 = torch.from_numpy(oracle.minhash_init(N_NODES, P).astype(np.int64))
-    hll0 = torch.from_numpy(oracle.hll_init(N_NODES, HLL_P).view(np.int8))
+    mh0 = torch.from_numpy(oracle.minhash_init(n, P).astype(np.int64))
+    hll0 = torch.from_numpy(oracle.hll_init(n, HLL_P).view(np.int8))
     t0 = time.perf_counter()
-    tables, cards = tr.build_tables(N_NODES, torch.from_numpy(ei), H, mh0, hll0, HLL_P, t.alpha, t.threshold, raw, bias, hops_to_run=H)
+    tables, cards = tr.build_tables(n, torch.from_numpy(ei), h, mh0, hll0, HLL_P, t.alpha, t.threshold, raw, bias, hops_to_run=h)
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
-    tr.pair_intersections(torch.from_numpy(links), tables, H, P, HLL_P, t.alpha, t.threshold, raw, bias)
+    tr.pair_intersections(torch.from_numpy(links), tables, h, P, HLL_P, t.alpha, t.threshold, raw, bias)
     t_query = time.perf_counter() - t0
-    return {'value': BATCH / (t_build + t_query), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-            'sample': f'reference-style torch CPU ops, 1 full step: {H}-hop build {t_build:.2f} s + '
-                      f'{BATCH}-pair query ({t_query:.3f} s); torch threads = {torch.get_num_threads()}'}
+    return {'value': batch / (t_build + t_query), 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+            'sample': f'reference-style torch CPU ops, 1 full step: {h}-hop build {t_build:.2f} s + '
+                      f'{batch}-pair query ({t_query:.3f} s); torch threads = {torch.get_num_threads()}'}
 
 
 def main():
@@ -150,19 +137,26 @@ def main():
     ap.add_argument('--config', default='collab', choices=sorted(CONFIGS), help='synthetic shape (default: BASELINE configs[1])')
     ap.add_argument('--graph', default='uniform', choices=['uniform', 'powerlaw'])
     ap.add_argument('--alpha', type=float, default=0.5, help='power-law exponent of the endpoint weights')
+    ap.add_argument('--batch', type=int, default=None, help='pairs per query batch (default: the config\'s)')
     ap.add_argument('--api', default='build_query', choices=['build_query', 'elph', 'buddy'],
                     help='build_query (default, the BASELINE metric): build_hash_tables + get_subgraph_features per step; '
                          'elph: the exact call sequence of ELPH.forward (models/elph.py:186-213) + one query per step; '
-                         'buddy: one build amortised over --buddy-batches query batches (datasets/elph.py:200-208)')
-    ap.add_argument('--buddy-batches', type=int, default=40)
+                         'buddy: one build amortised over --buddy-links pairs (datasets/elph.py:200-208)')
+    ap.add_argument('--buddy-links', type=int, default=None,
+                    help='pairs per BUDDY precompute (default: min(the config\'s L, 64 batches)); a step = the build + all of them')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='N > 1. weak (default): every rank its own batch, replicated build (N x by construction); strong: one '
+                         'global batch / link set sharded across the ranks (BASELINE configs[3], [4])')
     ap.add_argument('--build', default='replicated', choices=['replicated', 'sharded'],
                     help='N > 1 only. replicated (default): every rank builds the whole table; sharded: destination rows split '
                          'across ranks + in-place all-gather after every hop (pays off at ogbl-ppa / citation2 sizes)')
-    ap.add_argument('--time-all-kernels', action='store_true', help='HIP-event spans around every launch (default: only the roofline kernel)')
+    ap.add_argument('--sustain-seconds', type=float, default=1.0, help='length of the sustained run after the timed region (0 = skip)')
+    ap.add_argument('--no-kernel-table', action='store_true', help='skip the per-kernel HIP-event table (extra steps after the timed region)')
     a = ap.parse_args()
-    global N_NODES, E_UND, H, BATCH, GRAPH_KIND, PL_ALPHA
     cfg = CONFIGS[a.config]
-    N_NODES, E_UND, H, BATCH, GRAPH_KIND, PL_ALPHA = cfg['n'], cfg['e_und'], cfg['h'], cfg['batch'], a.graph, a.alpha
+    n, e_und, h = cfg['n'], cfg['e_und'], cfg['h']
+    batch = a.batch or cfg['batch']
+    e_dir = 2 * e_und
 
     launched = 'RANK' in os.environ  # under torchrun (also with one rank, so the RCCL path can be smoke-tested)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -178,46 +172,28 @@ def main():
     assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {a.gpus}'
 
     import subgraph_sketching_amd as ssa
-    from subgraph_sketching_amd import hashing
-    ssa._native.lib()  # fail loudly if the HIP engine is missing
-    eh = ssa.ElphHashes(Namespace(max_hash_hops=H, hll_p=HLL_P, minhash_num_perm=P, floor_sf=False, use_zero_one=True))
+    from subgraph_sketching_amd import roofline as rf
+    nat = ssa._native
+    lib = nat.lib()  # fails loudly if the HIP engine is missing
+    eh = ssa.ElphHashes(Namespace(max_hash_hops=h, hll_p=HLL_P, minhash_num_perm=P, floor_sf=False, use_zero_one=True))
     eh.strict_bounds = False  # no host sync inside a step
+    nf = h * (h + 2)
 
-    ei_np = synthetic_graph()
-    links_np = synthetic_links(2 + rank)
+    plan = ssa.dist.BatchPlan(a.scaling, world, rank, batch)
+    ei_np = synthetic_graph(n, e_und, a.graph, a.alpha)
+    links_np = synthetic_links(n, batch, plan.links_seed)
     ei = torch.from_numpy(ei_np).to(dev)
-    links = torch.from_numpy(links_np).to(dev)
-    # the per-batch feature gather runs on RCCL's stream UNDER the next step's build (double-buffered); every gather is
-    # completed inside the timed region (drain() before the closing fence)
-    gathered = [torch.empty((world * BATCH, H * (H + 2)), dtype=torch.float32, device=dev) for _ in range(2)] if launched else None
-    inflight = {'works': [], 'n': 0}
-
-    def gather(f):
-        if not launched:
-            return
-        # collectives of one process group run in issue order on RCCL's stream, so the buffer written two gathers ago is free
-        # again without the compute stream ever waiting for a gather; torch keeps `f` alive (record_stream) until it was read
-        inflight['works'].append((dist.all_gather_into_tensor(gathered[inflight['n'] % 2], f, async_op=True), f))
-        inflight['n'] += 1
-        if len(inflight['works']) > 4:  # host-side bookkeeping only: the oldest ones finished steps ago
-            inflight['works'].pop(0)[0].wait()
-
-    def drain():
-        for work, _ in inflight['works']:
-            work.wait()
-        inflight['works'].clear()
-
+    links = plan.local(torch.from_numpy(links_np).to(dev)).contiguous()
+    gather = ssa.dist.AsyncFeatureGather(plan, nf, dev) if launched else (lambda f: f)
     sharded_build = launched and world > 1 and a.build == 'sharded'
 
     def build_tables():
         if sharded_build:
-            return ssa.dist.sharded_build_hash_tables(eh, N_NODES, ei)
-        return eh.build_hash_tables(N_NODES, ei)
+            return ssa.dist.sharded_build_hash_tables(eh, n, ei)
+        return eh.build_hash_tables(n, ei)
 
-    # SURVEY 8(d) asks for T_build and the query rate beside the combined figure: measured on a few EXTRA steps after the timed
-    # region (three event records cost a step about 2 %, so the timed steps carry none)
-    phase_marks = []
     stream = torch.cuda.current_stream(dev)
+    phase_marks = []
 
     def step_build_query(mark=False):
         if mark:
@@ -235,15 +211,15 @@ def main():
 
     elph_state = {}
 
-    def step_elph():
+    def step_elph(mark=False):
         """what reference models/elph.py:186-213 + runners/train.py:204 execute per training step"""
-        loops = torch.arange(N_NODES, device=dev).repeat(2, 1)
+        loops = torch.arange(n, device=dev).repeat(2, 1)
         hash_edge_index = torch.cat([ei, loops], dim=1)                      # add_self_loops
         if 'mh0' not in elph_state:                                          # init once (elph.py:189-192)
-            elph_state['mh0'], elph_state['hll0'] = eh.initialise_minhash(N_NODES), eh.initialise_hll(N_NODES)
+            elph_state['mh0'], elph_state['hll0'] = eh.initialise_minhash(n), eh.initialise_hll(n)
         table = {0: {'minhash': elph_state['mh0'], 'hll': elph_state['hll0']}}
-        cards = torch.zeros((N_NODES, H), device=dev)
-        for k in range(1, H + 1):
+        cards = torch.zeros((n, h), device=dev)
+        for k in range(1, h + 1):
             table[k] = {'hll': eh.hll_prop(table[k - 1]['hll'], hash_edge_index),
                         'minhash': eh.minhash_prop(table[k - 1]['minhash'], hash_edge_index)}
             cards[:, k - 1] = eh.hll_count(table[k]['hll'])
@@ -251,19 +227,25 @@ def main():
         gather(f)
         return f
 
-    def step_buddy():
-        """one build, then --buddy-batches batches of B pairs; a 'step' is one batch incl. its share of the build"""
+    # BUDDY: the link set is a multiple of the batch; strong scaling shards every batch (the same slice of fresh pairs)
+    buddy_links = a.buddy_links or min(cfg['buddy_links'], 64 * batch)
+    buddy_batches = max(1, math.ceil(buddy_links / batch))
+
+    def step_buddy(mark=False):
+        """one build, then the whole link set in batches of B pairs (datasets/elph.py:200-208)"""
         table, cards = build_tables()
-        for _ in range(a.buddy_batches):
+        for _ in range(buddy_batches):
             f = eh.get_subgraph_features(links, table, cards)
             gather(f)
         return f
 
     step = {'build_query': step_build_query, 'elph': step_elph, 'buddy': step_buddy}[a.api]
-    pairs_per_step = BATCH * (a.buddy_batches if a.api == 'buddy' else 1)
+    batches_per_step = buddy_batches if a.api == 'buddy' else 1
+    pairs_per_step = plan.pairs_per_step * batches_per_step  # whole job, all ranks
 
     def fence():
-        drain()
+        if launched:
+            gather.drain()
         torch.cuda.synchronize(dev)
         if launched:
             dist.barrier()
@@ -271,91 +253,135 @@ def main():
 
     for _ in range(a.warmup):
         feats = step()
-    timer = KernelTimer(None if a.time_all_kernels else set())
-    hashing.KERNEL_TIMER = timer
-    lib = ssa._native.lib()
-    lib.ss_profile_enable(1 << ssa._native.PROF_MINHASH_HOP)  # HIP events around every launch of the dominant kernel (MinHash table hop), on its stream
+    lib.ss_profile_enable(1 << nat.PROF_MINHASH_HOP)  # HIP events around every launch of the dominant kernel, on its stream
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         feats = step()
     fence()
     elapsed = time.perf_counter() - t0
-    hashing.KERNEL_TIMER = None
-    from ctypes import byref, c_float, c_int32
     dom_ms, dom_n = c_float(), c_int32()
-    lib.ss_profile_read(ssa._native.PROF_MINHASH_HOP, byref(dom_ms), byref(dom_n))  # the launches of the timed region only
+    lib.ss_profile_read(nat.PROF_MINHASH_HOP, byref(dom_ms), byref(dom_n))  # the launches of the timed region only
     lib.ss_profile_enable(0)
-    if a.api == 'build_query':
-        for _ in range(5):
-            step_build_query(mark=True)
-        fence()
     if launched:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    ms_per_step = 1e3 * elapsed / a.steps
 
-    prop_ms, prop_n = timer.mean_ms('propagate')
-    prop_call_ms = prop_ms
-    pair_ms, pair_n = timer.mean_ms('pair_features')
-    csr_ms, _ = timer.mean_ms('csr_build')
-    first_ms, _ = timer.mean_ms('first_hop')
-    e_prime = 2 * E_UND + N_NODES
-    prop_bytes = (e_prime + N_NODES) * ROW_BYTES + 4 * e_prime + 8 * (N_NODES + 1) + 4 * N_NODES
-    roof_kernel = 'ss::propagate_kernel<128,256> (two-sketch launch)'
-    if dom_n.value:  # the library launches the MinHash and HLL hops separately: the MinHash table hop is the dominant kernel
-        prop_ms, prop_n = dom_ms.value, dom_n.value
-        prop_bytes = (e_prime + N_NODES) * 4 * P + 4 * e_prime + 8 * (N_NODES + 1)
-        roof_kernel = 'ss::propagate_kernel<128,256> (MinHash table hop: (E\'+N)*4P + 4E\' + 8(N+1) bytes)'
-        if sharded_build:  # each launch covers this rank's N/G destination rows and (on the uniform graph) E'/G in-edges
-            prop_bytes //= world
-            roof_kernel += f' / {world} ranks (row-sharded build)'
-    pair_bytes = BATCH * (2 * H * ROW_BYTES + 16 + 8 * H + 4 * H * (H + 2))
-    traffic = None
+    # ---- everything below runs AFTER the timed region ----------------------------------------------------------------
+    sustained = None
+    if a.sustain_seconds > 0:  # a region long enough for external samplers (the driver's gpu_busy probe) to see
+        reps = max(a.steps, int(math.ceil(a.sustain_seconds * 1e3 / ms_per_step)))
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        fence()
+        sustained = {'ms_per_step': 1e3 * (time.perf_counter() - t0) / reps, 'steps': reps}
+    if a.api == 'build_query':
+        for _ in range(5):
+            step_build_query(mark=True)
+        fence()
+    kernel_table = None
+    if not a.no_kernel_table:
+        tags = {'csr_build': nat.PROF_CSR, 'first_hop_hll': nat.PROF_FIRST_HOP_HLL, 'first_hop_minhash': nat.PROF_FIRST_HOP_MH,
+                'hll_hop': nat.PROF_HLL_HOP, 'minhash_hop': nat.PROF_MINHASH_HOP, 'hub_passes': nat.PROF_HUB,
+                'pair_features': nat.PROF_PAIRS}
+        lib.ss_profile_enable(sum(1 << t for t in tags.values()))
+        extra = 5
+        for _ in range(extra):
+            step()
+        fence()
+        lib.ss_profile_enable(0)
+        model = rf.kernel_bytes(n, e_dir, P, HLL_P, h, links.size(0))
+        kernel_table = {}
+        for name, tag in tags.items():
+            ms, cnt = c_float(), c_int32()
+            lib.ss_profile_read(tag, byref(ms), byref(cnt))
+            if not cnt.value:
+                continue
+            row = {'mean_launch_ms': ms.value, 'launches_per_step': cnt.value / extra}
+            if name in model and not (sharded_build and name != 'pair_features' and name != 'csr_build'):
+                row['algorithmic_bytes'] = model[name]
+                row['frac_of_hbm_peak'] = model[name] / (ms.value * 1e-3) / 1e9 / rf.HBM_PEAK_GBS
+            kernel_table[name] = row
+        kernel_table['note'] = ('HIP-event brackets inside the library on the launch stream (include ~5 us of dispatch each); csr_build '
+                                'spans all launches of one build; hub_passes = the hub / mega-row launches of every hop')
+
+    # ---- roofline of the dominant kernel -----------------------------------------------------------------------------
+    prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch)['minhash_hop']
+    roof_kernel = "ss::propagate_kernel<128,256> (MinHash table hop: (E'+N)*4P + 4E + 8(N+1) bytes)"
+    if sharded_build:  # each launch covers this rank's N/G destination rows and (on the uniform graph) E'/G in-edges
+        prop_bytes //= world
+        roof_kernel += f' / {world} ranks (row-sharded build)'
+    prop_ms, prop_n = dom_ms.value, dom_n.value
+    achieved = prop_bytes / (prop_ms * 1e-3) / 1e9 if prop_ms else None
+    profiled = None
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and a.config == 'collab' and a.graph == 'uniform' and not sharded_build:
         with open(pmc_path) as fh:
-            traffic = json.load(fh).get('propagate_kernel_hbm_bytes_per_launch')
-
+            blob = json.load(fh)
+        profiled = {'bytes_per_launch': blob.get('propagate_kernel_hbm_bytes_per_launch'), 'file': 'profiles/pmc_traffic.json',
+                    'collected': blob.get('collected', 'separate rocprofv3 --pmc passes of this command (tools/prof.sh), not this run'),
+                    'note': 'FETCH_SIZE counts fabric requests including Infinity-Cache hits: it shows the absence of L2 re-reads, '
+                            'it is not an HBM byte count'}
+    step_bytes = rf.step_bytes_implemented(n, e_dir, P, HLL_P, h, links.size(0))
+    step_ok = a.api == 'build_query' and not sharded_build
     out = {
         'metric': 'edge-pairs/sec subgraph-feature extraction (build+query)',
-        'value': world * pairs_per_step * a.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps,
-        'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'value': pairs_per_step * a.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps,
+        'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': a.scaling,
         'vs_baseline': None, 'dtype': 'u32/u8 sketches, f32 estimator', 'data': 'synthetic',
         'config': {'workload': f'ogbl-{a.config}-like synthetic {a.graph} graph' + (' (BASELINE configs[1])' if a.config == 'collab' else '') +
                                ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps' +
-                               ('' if a.api == 'build_query' else f' [api mode: {a.api}]'),
-                   'num_nodes': N_NODES, 'directed_edges': 2 * E_UND, 'max_hash_hops': H, 'minhash_num_perm': P, 'hll_p': HLL_P,
-                   'pairs_per_step_per_gpu': pairs_per_step, 'global_pairs_per_step': world * pairs_per_step,
-                   'parallelism': f'edge-batch sharded x{world}, all_gather of features; sketch table ' +
-                                  (f'built row-sharded x{world} with an in-place all_gather per hop and sketch' if sharded_build
-                                   else 'replicated (every rank builds it)'),
-                   'hll_tables': eh.hll_tables.provenance},
-        'roofline': {'kernel': roof_kernel + ('' if H > 1 else ' (not launched at h=1)') +
-                               (' [elph api mode launches it per sketch: the bytes model below does not apply]' if a.api == 'elph' else ''), 'bound': 'hbm', 'achieved': prop_bytes / (prop_ms * 1e-3) / 1e9 if prop_ms else None,
-                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': prop_bytes / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if prop_ms else None, 'traffic': traffic,
-                     'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n}
+                               ('' if a.api == 'build_query' else f' [api mode: {a.api}' + (f', {buddy_batches} batches per build' if a.api == 'buddy' else '') + ']'),
+                   'num_nodes': n, 'directed_edges': e_dir, 'max_hash_hops': h, 'minhash_num_perm': P, 'hll_p': HLL_P,
+                   'pairs_per_step_per_gpu': links.size(0) * batches_per_step, 'global_pairs_per_step': pairs_per_step,
+                   'parallelism': (f'edge batches sharded x{world} ({a.scaling} scaling), all_gather of features; sketch table ' +
+                                   (f'built row-sharded x{world} with an in-place all_gather per hop and sketch' if sharded_build
+                                    else 'replicated (every rank builds it)')),
+                   'hll_tables': eh.tables_id},
+        'roofline': {'kernel': roof_kernel + ('' if h > 1 else ' (not launched at h=1)') +
+                               (' [elph api mode launches it per sketch: the same kernel and bytes]' if a.api == 'elph' else ''),
+                     'bound': 'hbm', 'achieved': achieved, 'peak': rf.HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / rf.HBM_PEAK_GBS if achieved else None, 'traffic': None, 'traffic_profiled': profiled,
+                     'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n,
+                     'resident': rf.residency(n, 'minhash_hop', P, HLL_P),
+                     'unique_hbm_bytes_per_launch': rf.unique_bytes(n, e_dir, 'minhash_hop', P, HLL_P) // (world if sharded_build else 1),
+                     'note': 'resident = infinity-cache: the gathered table (N*4P bytes) fits the 256 MiB Infinity Cache, so `achieved` is a '
+                             'fabric + cache rate and may exceed what HBM alone streams (~6.3 TB/s); see --config citation2 for the HBM-resident case'},
     }
+    if step_ok:
+        out['step_roofline'] = {'bound': 'hbm', 'bytes_per_step': step_bytes, 'ms_per_step': ms_per_step,
+                                'achieved': step_bytes / (ms_per_step * 1e-3) / 1e9, 'peak': rf.HBM_PEAK_GBS, 'unit': 'GB/s',
+                                'frac': step_bytes / (ms_per_step * 1e-3) / 1e9 / rf.HBM_PEAK_GBS,
+                                'bytes_per_step_survey_definition': rf.step_bytes_survey(n, e_dir, P, HLL_P, h, links.size(0)),
+                                'note': 'bytes of the IMPLEMENTED schedule (CSR build, hop 1 from node ids without table reads, h-1 table '
+                                        'hops, query) over the whole step time incl. launch gaps; the SURVEY 8(d) definition counts a table '
+                                        'read for hop 1 too, which this schedule does not perform'}
+    if sustained:
+        out['sustained'] = dict(sustained, pairs_per_s=pairs_per_step / (sustained['ms_per_step'] * 1e-3),
+                                note='same step, run back to back for >= --sustain-seconds after the timed region')
     if phase_marks:
         build_ms = sum(s0.elapsed_time(s1) for s0, s1, _ in phase_marks) / len(phase_marks)
         query_ms = sum(s1.elapsed_time(s2) for _, s1, s2 in phase_marks) / len(phase_marks)
         out['breakdown'] = {'build_ms': build_ms, 'query_ms': query_ms,
-                            'build_directed_edges_per_s': H * (2 * E_UND + N_NODES) / (build_ms * 1e-3),  # h * E' / T_build
-                            'query_pairs_per_s': BATCH / (query_ms * 1e-3), 'scope': 'this rank, HIP events on the launch stream'}
-    if a.time_all_kernels:  # host-side HIP-event spans around every library call (perturbs the step by ~7 %)
-        out['kernels'] = {'propagate_call_ms': prop_call_ms, 'first_hop_call_ms': first_ms, 'pair_features_ms': pair_ms,
-                          'csr_build_ms': csr_ms, 'pair_features_algorithmic_bytes': pair_bytes,
-                          'pair_features_GBps': pair_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms else None,
-                          'query_only_pairs_per_s': BATCH / (pair_ms * 1e-3) if pair_ms else None}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config in ('collab', 'cora'):
-        base, ofeat = cpu_baseline(ei_np, links_np)
+                            'build_directed_edges_per_s': h * (e_dir + n) / (build_ms * 1e-3),  # h * E' / T_build
+                            'query_pairs_per_s': links.size(0) / (query_ms * 1e-3), 'scope': 'this rank, HIP events on the launch stream'}
+        if not sharded_build:  # what every rank repeats: the whole build
+            out['redundant_fraction_of_step'] = build_ms / (build_ms + query_ms) if world > 1 else 0.0
+            out['redundant_note'] = ('replicated build: every rank repeats it; under weak scaling the N-GPU rate is ~N x by construction'
+                                     if world > 1 else 'single GPU: nothing is repeated')
+    if kernel_table:
+        out['kernels'] = kernel_table
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config in ('collab', 'cora') and a.api == 'build_query' and batch == cfg['batch']:
+        base, ofeat = cpu_baseline(ei_np, links_np, n, h, batch)
         out['cpu_baseline'] = base
-        diff = float(np.abs(feats.cpu().numpy() - ofeat).max())
-        out['cpu_baseline']['max_abs_feature_diff_vs_gpu'] = diff
+        out['cpu_baseline']['max_abs_feature_diff_vs_gpu'] = float(np.abs(feats.cpu().numpy() - ofeat).max())
         out['speedup_vs_cpu_baseline'] = out['value'] / base['value']
         if a.config == 'collab':
-            out['cpu_baseline_reference_style'] = cpu_baseline_reference_style(ei_np, links_np)
+            out['cpu_baseline_reference_style'] = cpu_baseline_reference_style(ei_np, links_np, n, h, batch)
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:

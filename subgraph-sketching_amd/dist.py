@@ -88,3 +88,87 @@ def sharded_build_hash_tables(eh, num_nodes, edge_index, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return eh.build_hash_tables(num_nodes, edge_index)
     return eh._build(num_nodes, edge_index, RowShard(num_nodes, group))
+
+
+# ---- workload bookkeeping shared by bench.py and the gloo tests ------------------------------------------------------
+class BatchPlan(object):
+    """which pairs of a step a rank owns, and what a step counts for.
+
+    weak   : per-GPU work fixed -- every rank has its OWN `batch` pairs (the caller seeds them per rank); a step processes
+             world * batch pairs.  With a replicated build the N-GPU rate is ~N x the 1-GPU rate BY CONSTRUCTION (every rank
+             repeats the build); it measures the collective machinery, not the sharding.
+    strong : total work fixed -- ONE global batch of `batch` pairs (BASELINE configs[3] / [4]: "edge-batch sharded across
+             8"), rank r owns the contiguous slice shard_bounds(batch, world, r); a step processes `batch` pairs whatever
+             the world size, so value(N) / value(1) is the speed-up of the same job."""
+
+    def __init__(self, scaling, world, rank, batch):
+        if scaling not in ('weak', 'strong'):
+            raise ValueError(f'scaling must be weak or strong, got {scaling}')
+        self.scaling, self.world, self.rank, self.batch = scaling, world, rank, batch
+        if scaling == 'weak':
+            self.lo, self.hi = 0, batch
+            self.rows_per_rank = batch
+            self.pairs_per_step = world * batch
+            self.links_seed = 2 + rank  # every rank draws its own pairs
+        else:
+            self.lo, self.hi = shard_bounds(batch, world, rank)
+            self.rows_per_rank = (batch + world - 1) // world  # gather block (the last ranks pad)
+            self.pairs_per_step = batch
+            self.links_seed = 2         # every rank draws the SAME global batch and slices it
+        self.local_pairs = self.hi - self.lo
+
+    def local(self, links):
+        """this rank's slice of the batch tensor it generated with `links_seed`"""
+        return links if self.scaling == 'weak' else links[self.lo:self.hi]
+
+    def unpad(self, gathered):
+        """[world * rows_per_rank, F] as gathered -> the rows of the step in order (strong: drops the padding rows)"""
+        if self.scaling == 'weak' or self.world * self.rows_per_rank == self.batch:
+            return gathered
+        per, keep = self.rows_per_rank, []
+        for r in range(self.world):
+            lo, hi = shard_bounds(self.batch, self.world, r)
+            keep.append(gathered[r * per:r * per + (hi - lo)])
+        return torch.cat(keep, dim=0)
+
+
+class AsyncFeatureGather(object):
+    """per-batch all_gather of the feature rows, issued asynchronously (RCCL: on its own stream, under the next step's
+    kernels) into `depth` rotating output buffers; collectives of one group run in issue order, so the buffer written
+    `depth` gathers ago is free again without the compute stream ever waiting.  drain() completes everything (bench.py
+    calls it inside the timed region, before the closing fence).  Works unchanged on gloo / CPU tensors (tests)."""
+
+    def __init__(self, plan, num_features, device, dtype=torch.float32, depth=2, group=None):
+        self.plan, self.group, self.depth = plan, group, depth
+        self.active = dist.is_available() and dist.is_initialized()
+        self.out = [torch.empty((plan.world * plan.rows_per_rank, num_features), dtype=dtype, device=device)
+                    for _ in range(depth)] if self.active else None
+        self.pad = ([torch.zeros((plan.rows_per_rank, num_features), dtype=dtype, device=device) for _ in range(depth)]
+                    if self.active and plan.scaling == 'strong' else None)
+        self.slot_work = [None] * depth  # the gather that last used slot i (its pad as input, its buffer as output)
+        self.works, self.issued = [], 0
+
+    def __call__(self, feats):
+        """feats: this rank's [local_pairs, F]; returns the buffer the gather lands in (valid after drain / wait)"""
+        if not self.active:
+            return feats
+        slot = self.issued % self.depth
+        if self.slot_work[slot] is not None:
+            self.slot_work[slot].wait()  # stream-ordered: the current stream waits for that gather, the host does not block
+        src = feats
+        if feats.size(0) != self.plan.rows_per_rank:  # strong scaling, ragged last shard: pad to the common block size
+            self.pad[slot][:feats.size(0)].copy_(feats)
+            src = self.pad[slot]
+        dst = self.out[slot]
+        work = dist.all_gather_into_tensor(dst, src.contiguous(), group=self.group, async_op=True)
+        self.works.append((work, src))
+        self.slot_work[slot] = work
+        self.issued += 1
+        if len(self.works) > 2 * self.depth:  # host-side bookkeeping only: the oldest ones finished steps ago
+            self.works.pop(0)[0].wait()
+        return dst
+
+    def drain(self):
+        for work, _ in self.works:
+            work.wait()
+        self.works.clear()

@@ -1,0 +1,75 @@
+"""Byte model of the hot path: the algorithmic bytes every kernel family moves per launch under the IMPLEMENTED schedule
+(DESIGN.md section 3 states each formula), the bytes a step would move under SURVEY.md 8(d)'s per-hop definition, and
+where a launch's working set lives.  Pure arithmetic -- used by bench.py for the `roofline` / `step_roofline` objects and
+checked by tests/test_host_logic.py; nothing here touches a device.
+
+Symbols: N nodes, E directed edges as given (edge_index columns), E' = E + N (the reference appends one self loop per node,
+hashing.py:148; here they are implicit: `col` holds E entries, the walk visits E' rows), P MinHash permutations (u32 each),
+M = 2^p HLL registers (u8 each), R = 4P + M bytes per sketch row, h hops, B pairs per query batch.
+"""
+
+HBM_PEAK_GBS = 8000.0           # MI355X spec (MI355X_MICROARCH.md); a float4 copy reaches 6.29 TB/s (79 %)
+INFINITY_CACHE_BYTES = 256 << 20  # MALL / L3; FETCH_SIZE counts fabric requests INCLUDING the ones it serves
+
+
+def csr_bytes(N, E):
+    """ss_csr_build, single partition pass + finish (the shape of every BASELINE config): count_keys reads dst (8E);
+    scatter_tiles reads src + dst (16E) and writes the staged int2 pairs (8E); finish reads the staged pairs twice (count,
+    place: 16E) and writes col (4E) + rowptr (8(N+1)).  A second / third partition pass adds 24E each (N > 262 144)."""
+    passes = 1 if N <= 256 * 1024 else 2
+    return 8 * E + (16 * E + 8 * E) + (passes - 1) * (8 * E + 16 * E) + 16 * E + 4 * E + 8 * (N + 1)
+
+
+def graph_read_bytes(N, E):
+    """what every propagation launch reads of the CSR: col (4E) + rowptr (8(N+1))"""
+    return 4 * E + 8 * (N + 1)
+
+
+def kernel_bytes(N, E, P=128, p=8, h=2, B=65536):
+    """algorithmic bytes per LAUNCH of each kernel family of one step (build_hash_tables + one query batch)"""
+    M, Ep = 1 << p, E + N
+    return {
+        'csr_build': csr_bytes(N, E),
+        # hop 1 from node ids: no table reads (hop-0 rows are recomputed in registers)
+        'first_hop_hll': graph_read_bytes(N, E) + N * M + 4 * N,            # writes the HLL rows + cards[:, 0]
+        'first_hop_minhash': graph_read_bytes(N, E) + N * 4 * P,            # writes the MinHash rows
+        # table hops (k = 2..h): one input row per edge and self loop, one output row per node
+        'hll_hop': (Ep + N) * M + graph_read_bytes(N, E) + 4 * N,           # + cards[:, k-1]
+        'minhash_hop': (Ep + N) * 4 * P + graph_read_bytes(N, E),
+        'pair_features': B * pair_bytes(P, p, h),
+    }
+
+
+def pair_bytes(P=128, p=8, h=2):
+    """per pair: 2h sketch rows + the two int64 ids + 2h cardinalities + h(h+2) fp32 features"""
+    return 2 * h * (4 * P + (1 << p)) + 16 + 8 * h + 4 * h * (h + 2)
+
+
+def step_bytes_implemented(N, E, P=128, p=8, h=2, B=65536):
+    """bytes of one step under the implemented schedule: CSR build, hop 1 from node ids, h - 1 table hops, one query batch"""
+    k = kernel_bytes(N, E, P, p, h, B)
+    return (k['csr_build'] + k['first_hop_hll'] + k['first_hop_minhash'] + (h - 1) * (k['hll_hop'] + k['minhash_hop'])
+            + k['pair_features'])
+
+
+def step_bytes_survey(N, E, P=128, p=8, h=2, B=65536):
+    """h table hops of (E'+N)R + 4E' + 8(N+1) + 4N bytes + the query; CSR construction and hop-0
+    initialisation reported separately there.  Larger than the implemented schedule's bytes because hop 1 no longer reads
+    a table -- a step faster than this figure / 8 TB/s is therefore not a measurement error."""
+    R, Ep = 4 * P + (1 << p), E + N
+    return h * ((Ep + N) * R + 4 * Ep + 8 * (N + 1) + 4 * N) + B * pair_bytes(P, p, h)
+
+
+def unique_bytes(N, E, family, P=128, p=8):
+    """distinct HBM bytes a launch touches (each input row counted once however many edges read it): what the HBM
+    itself must deliver when the input table fits the Infinity Cache"""
+    M = 1 << p
+    row = {'minhash_hop': 4 * P, 'hll_hop': M}[family]
+    return 2 * N * row + graph_read_bytes(N, E) + (4 * N if family == 'hll_hop' else 0)
+
+
+def residency(N, family, P=128, p=8):
+    """'infinity-cache' when the table a hop gathers from fits the 256 MiB Infinity Cache (its random row reads are then
+    mostly served there and `achieved` can exceed what HBM alone streams), else 'hbm'"""
+    row = {'minhash_hop': 4 * P, 'hll_hop': 1 << p}[family]
+    return 'infinity-cache' if N * row <= INFINITY_CACHE_BYTES else 'hbm'

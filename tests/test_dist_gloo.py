@@ -126,3 +126,46 @@ def test_row_shard_bounds():
             assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
             assert per * world >= n
     assert ssa.dist.RowShard.__init__.__code__.co_argcount == 3
+
+
+# ---- bench.py's workload bookkeeping: BatchPlan + AsyncFeatureGather under both scaling modes -------------------------
+def _plan_worker(rank, world, port, batch, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import subgraph_sketching_amd as ssa
+    F = 8
+    results = {}
+    for scaling in ('strong', 'weak'):
+        plan = ssa.dist.BatchPlan(scaling, world, rank, batch)
+        links = torch.from_numpy(np.random.RandomState(plan.links_seed).randint(0, 1000, size=(batch, 2)).astype(np.int64))
+        mine = plan.local(links)
+        assert mine.size(0) == plan.local_pairs
+        gather = ssa.dist.AsyncFeatureGather(plan, F, torch.device('cpu'))
+        outs = []
+        for step in range(5):  # more gathers than buffers: slots are reused, the ragged shard is re-padded every time
+            feats = (mine[:, :1] * 10 + mine[:, 1:] + step).float().repeat(1, F)
+            outs.append((step, gather(feats)))
+        gather.drain()
+        step, buf = outs[-1]
+        got = plan.unpad(buf)
+        if scaling == 'strong':  # every rank generated the same global batch: the gathered rows are the whole batch in order
+            want = (links[:, :1] * 10 + links[:, 1:] + step).float().repeat(1, F)
+            assert got.shape == (batch, F) and torch.equal(got, want), f'rank {rank} strong: gathered rows differ'
+        else:                    # rank r's block holds rank r's own pairs
+            assert got.shape == (world * batch, F)
+            for r in range(world):
+                lr = torch.from_numpy(np.random.RandomState(2 + r).randint(0, 1000, size=(batch, 2)).astype(np.int64))
+                assert torch.equal(got[r * batch:(r + 1) * batch], (lr[:, :1] * 10 + lr[:, 1:] + step).float().repeat(1, F))
+        results[scaling] = got
+    torch.save(results, os.path.join(out_dir, f'plan_rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('batch', [1001, 64, 3])
+def test_batch_plan_and_async_gather_world2(tmp_path, batch):
+    world = 2
+    mp.spawn(_plan_worker, args=(world, _free_port(), batch, str(tmp_path)), nprocs=world, join=True)
+    a, b = torch.load(tmp_path / 'plan_rank0.pt'), torch.load(tmp_path / 'plan_rank1.pt')
+    assert torch.equal(a['strong'], b['strong']) and torch.equal(a['weak'], b['weak'])

@@ -240,3 +240,39 @@ def test_exported_datasketch_tables_are_preferred_over_regenerated(ssa, tmp_path
     with pytest.raises(ImportError):
         monkeypatch.setattr(ht, 'EXPORTED', '/nonexistent.npz')
         ht.load(8, prefer='datasketch')
+
+
+def test_byte_model_of_the_step(ssa):
+    """subgraph_sketching_amd/roofline.py: the figures bench.py's roofline objects are built from"""
+    rf = ssa.roofline
+    n, e = 235868, 2358104                      # the bench graph (BASELINE configs[1])
+    k = rf.kernel_bytes(n, e, 128, 8, 2, 65536)
+    ep = e + n
+    assert k['minhash_hop'] == (ep + n) * 512 + 4 * e + 8 * (n + 1)
+    assert k['hll_hop'] == (ep + n) * 256 + 4 * e + 8 * (n + 1) + 4 * n
+    assert k['pair_features'] == 65536 * 3136 and rf.pair_bytes(128, 8, 3) == 4708 and rf.pair_bytes(128, 8, 1) == 1572
+    assert abs(k['minhash_hop'] - 1.4611e9) < 5e6                   # DESIGN 3.1: 1.461 GB per launch
+    survey = rf.step_bytes_survey(n, e, 128, 8, 2, 65536)
+    assert abs(survey - (2 * 2.187e9 + 0.2055e9)) < 2e7             # VERDICT r1 weak #5: 4.58 GB per step by SURVEY 8(d)
+    impl = rf.step_bytes_implemented(n, e, 128, 8, 2, 65536)
+    assert impl < survey and abs(impl - 2.74e9) < 0.1e9             # hop 1 reads no table: ~2.7 GB per step
+    assert rf.residency(n, 'minhash_hop') == 'infinity-cache' and rf.residency(2927963, 'minhash_hop') == 'hbm'
+    assert rf.residency(576289, 'minhash_hop') == 'hbm' and rf.residency(576289, 'hll_hop') == 'infinity-cache'
+    assert rf.unique_bytes(n, e, 'minhash_hop') == 2 * n * 512 + 4 * e + 8 * (n + 1)
+    assert rf.csr_bytes(n, e) == 52 * e + 8 * (n + 1) and rf.csr_bytes(576289, e) == 76 * e + 8 * 576290
+
+
+def test_batch_plan_bookkeeping(ssa):
+    """weak: every rank its own batch; strong: one global batch cut into contiguous slices that tile it"""
+    BatchPlan = ssa.dist.BatchPlan
+    for batch in (65536, 131072, 261424, 7, 1):
+        for world in (1, 2, 4, 8):
+            plans = [BatchPlan('strong', world, r, batch) for r in range(world)]
+            assert plans[0].lo == 0 and plans[-1].hi == batch and all(a.hi == b.lo for a, b in zip(plans, plans[1:]))
+            assert all(p.pairs_per_step == batch and p.links_seed == 2 for p in plans)
+            assert all(p.local_pairs <= p.rows_per_rank for p in plans) and world * plans[0].rows_per_rank >= batch
+            weak = [BatchPlan('weak', world, r, batch) for r in range(world)]
+            assert all(p.pairs_per_step == world * batch and p.local_pairs == batch for p in weak)
+            assert len({p.links_seed for p in weak}) == world
+    with pytest.raises(ValueError):
+        BatchPlan('medium', 2, 0, 8)

@@ -296,3 +296,18 @@ def test_datasketch_tables_fixture():
         prm = oracle_params(t, with_lc=False)
         got = oracle.estimate_bias(g[f'estimate_p{p}'].astype(np.float32), prm, refine=True)
         np.testing.assert_allclose(got, g[f'corrected_p{p}'], rtol=2e-6, atol=2e-4 * (1 << p) / 256)
+
+
+def test_reference_elph_forward_fixture_vs_oracle(regenerated_tables):
+    """golden G12 (outputs of the reference's own ELPH.forward + its training-loop query) against the oracle"""
+    g = load_golden('g12_elph_forward.npz')
+    prm = _prm(regenerated_tables, 8)
+    for tag in ('ba', 'uni'):
+        n, h = int(g[f'{tag}_num_nodes']), int(g[f'{tag}_hops'])
+        tables, cards = oracle.build_hash_tables(n, g[f'{tag}_edge_index'], h, 128, prm)
+        if tag == 'ba':
+            for k in range(h + 1):
+                assert np.array_equal(tables[k]['minhash'], g[f'ba_t_mh_{k}']) and np.array_equal(tables[k]['hll'], g[f'ba_t_hll_{k}'])
+        np.testing.assert_allclose(cards, g[f'{tag}_cards'], rtol=RTOL, atol=ATOL)
+        feats = oracle.pair_features(g[f'{tag}_links'], tables, cards, h, prm)
+        np.testing.assert_allclose(feats, g[f'{tag}_feat'], rtol=RTOL, atol=ATOL * 10)

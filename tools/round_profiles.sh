@@ -1,0 +1,15 @@
+#!/bin/bash
+# usage (GPU box, via gpurun): bash tools/round_profiles.sh <prefix>   e.g. round2_v1
+# kernel-trace stats + the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) for the bench
+# shape and the three shapes whose tables do NOT fit the Infinity Cache / have hub rows:
+#   <prefix>            collab-like uniform (BASELINE configs[1], the driver's shape)
+#   <prefix>_ppa        ppa-like uniform (configs[3]; MinHash table 295 MB: HBM-resident)
+#   <prefix>_citation2  citation2-like uniform, h = 3 (configs[4]; 1.5 GB MinHash table: HBM-resident random gathers)
+#   <prefix>_powerlaw   collab-like, endpoint weights ~ rank^-0.5 (hub rows)
+# then: python tools/summarise_prof.py <tag> for each (run in the build container; copies the summaries into profiles/)
+P=$1
+R=$GRAFT_REPO_ROOT
+bash $R/tools/prof.sh $P
+bash $R/tools/prof.sh ${P}_ppa --config ppa --steps 10 --warmup 2
+bash $R/tools/prof.sh ${P}_citation2 --config citation2 --steps 5 --warmup 2
+bash $R/tools/prof.sh ${P}_powerlaw --graph powerlaw --alpha 0.5
