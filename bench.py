@@ -55,9 +55,10 @@ CONFIGS = {
     'citation2': dict(n=2927963, e_und=30387995, h=3, batch=261424, buddy_links=356_000_000),  # configs[4]
 }
 P, HLL_P = 128, 8
+N_NODES, E_UND, H, BATCH = (CONFIGS['collab'][k] for k in ('n', 'e_und', 'h', 'batch'))  # the bench shape, for the probes under tools/
 
 
-def synthetic_graph(n, e_und, kind='uniform', alpha=0.5, seed=1):
+def synthetic_graph(n=N_NODES, e_und=E_UND, kind='uniform', alpha=0.5, seed=1):
     rng = np.random.RandomState(seed)
     if kind == 'uniform':
         e = rng.randint(0, n, size=(2, e_und)).astype(np.int64)
@@ -69,7 +70,7 @@ def synthetic_graph(n, e_und, kind='uniform', alpha=0.5, seed=1):
     return np.concatenate([e, e[::-1]], axis=1)
 
 
-def synthetic_links(n, batch, seed):
+def synthetic_links(n=N_NODES, batch=BATCH, seed=2):
     return np.random.RandomState(seed).randint(0, n, size=(batch, 2)).astype(np.int64)
 
 

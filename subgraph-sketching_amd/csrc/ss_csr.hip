@@ -33,6 +33,7 @@ constexpr int kMaxKeys = 256;          // partition fan-out per pass
 constexpr int kMaxBlocks1 = 2048;      // pass-1 slices
 constexpr int kFinishThreads = 512;
 constexpr int kFinishCap = 16384;      // edges staged in LDS by the finish step (64 KiB)
+constexpr int kMaxTiles = 1536;        // single-pass plan: tiles whose run descriptors fit the finish step's LDS beside the image (2 workgroups per CU)
 
 struct CsrPlan {
     int node_shift;       // fine bucket = dst >> node_shift
@@ -48,6 +49,8 @@ struct CsrPlan {
     int shift2;           // pass-2 key = dst >> shift2 (three_pass only; otherwise pass 2 keys on node_shift)
     int keys3, parts3;
     int64_t groups3;      // keys1 * keys2 pass-2 buckets, each partitioned by pass 3
+    bool gather;          // single-pass plan in two launches: tile_sort_kernel + finish_gather_kernel
+    int tiles;            // 4096-edge tiles (gather plan)
 };
 
 inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
@@ -101,6 +104,8 @@ inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
     if (parts < 1) parts = 1;
     if (parts > 64) parts = 64;
     p.parts2 = parts;
+    p.tiles = (int)((E + kTile - 1) / kTile);
+    p.gather = !p.two_pass && E > 0 && (E + kTile - 1) / kTile <= kMaxTiles && !getenv("SS_CSR_NO_GATHER");
     return true;
 }
 
@@ -115,6 +120,8 @@ struct Workspace {
     unsigned long long *fine_base3; // [fine_buckets + 1]
     unsigned long long *scratch;    // [1] n_self when the caller does not want it
     int2 *staged_a, *staged_b;      // [E] each
+    uint32_t *tile_off;             // gather plan: [keys1 + 1][tiles]
+    unsigned long long *tile_max;   // gather plan: [tiles]
     size_t bytes;
 };
 
@@ -133,6 +140,8 @@ inline Workspace carve(const CsrPlan &p, int64_t E, void *base)
     w.scratch = reinterpret_cast<unsigned long long *>(take(8));
     w.staged_a = reinterpret_cast<int2 *>(take((size_t)(E > 0 ? E : 1) * 8));
     w.staged_b = reinterpret_cast<int2 *>(take(p.two_pass ? (size_t)(E > 0 ? E : 1) * 8 : 0));
+    w.tile_off = reinterpret_cast<uint32_t *>(take(p.gather ? (size_t)(p.keys1 + 1) * p.tiles * 4 : 0));
+    w.tile_max = reinterpret_cast<unsigned long long *>(take(p.gather ? (size_t)p.tiles * 8 : 0));
     w.bytes = off;
     return w;
 }
@@ -391,33 +400,89 @@ __global__ __launch_bounds__(kThreads) void scatter_tiles_kernel(PassArgs a, con
     }
 }
 
-// finish: one workgroup per fine bucket
-__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__restrict__ staged, const unsigned long long *__restrict__ fine_base,
-                                                                int node_shift, int64_t N, int64_t *__restrict__ rowptr,
-                                                                int32_t *__restrict__ col, int hub_threshold, int32_t *__restrict__ hub_rows,
-                                                                int32_t *__restrict__ hub_count, int32_t *__restrict__ mega_rows,
-                                                                int32_t *__restrict__ mega_count)
+// ---- finish: one workgroup per fine bucket --------------------------------------------------------------------------------
+// The bucket's edges reach the workgroup through an "edge source" with for_each(f): either one contiguous run of the staged
+// array (partition passes: ContiguousEdges) or one short run per 4096-edge tile of the tile-sorted array (single-pass plan:
+// GatheredEdges, see tile_sort_kernel).
+struct ContiguousEdges {
+    const int2 *staged;
+    unsigned long long seg_lo;
+    uint32_t seg_n;
+    template <typename F>
+    __device__ __forceinline__ void for_each(F &&f) const
+    {
+        for (uint32_t q0 = 0; q0 < seg_n; q0 += 4 * kFinishThreads) {
+            int2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t q = q0 + threadIdx.x + k * kFinishThreads;
+                v[k] = q < seg_n ? staged[seg_lo + q] : make_int2(0, -1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v[k].y >= 0) f(v[k]);
+        }
+    }
+};
+
+// LANES lanes read one tile's run; chosen from the average run length of the bucket (tile / buckets = ~18 edges on the bench
+// graph -> 32 lanes; skewed buckets whose runs are hundreds of edges -> whole wavefronts), so that most runs need one load
+template <int LANES>
+struct GatheredEdges {
+    const int2 *staged;
+    const uint32_t *seg;  // LDS [tiles]: run start inside the tile (low 16 bits) | run length << 16
+    int tiles;
+    template <typename F>
+    __device__ __forceinline__ void for_each(F &&f) const
+    {
+        constexpr int kGroups = kFinishThreads / LANES;
+        const int grp = threadIdx.x / LANES, l = threadIdx.x % LANES;
+        for (int t0 = grp; t0 < tiles; t0 += 4 * kGroups) {  // four runs requested per lane group before the first is consumed
+            int2 v[4];
+            uint32_t len[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = t0 + k * kGroups;
+                const uint32_t d = t < tiles ? seg[t] : 0u;
+                len[k] = d >> 16;
+                v[k] = (uint32_t)l < len[k] ? staged[(int64_t)t * kTile + (d & 0xFFFFu) + l] : make_int2(0, -1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (v[k].y >= 0) f(v[k]);
+                if (len[k] > (uint32_t)LANES) {  // the rest of a run longer than the lane group, two loads in flight
+                    const int t = t0 + k * kGroups;
+                    const int2 *run = staged + (int64_t)t * kTile + (seg[t] & 0xFFFFu);
+                    for (uint32_t q = LANES + l; q < len[k]; q += 2 * LANES) {
+                        const int2 a = run[q];
+                        const int2 b = q + LANES < len[k] ? run[q + LANES] : make_int2(0, -1);
+                        f(a);
+                        if (b.y >= 0) f(b);
+                    }
+                }
+            }
+        }
+    }
+};
+
+struct FinishLds {
+    uint32_t cnt[1024], excl[1024 + 1];
+    int32_t image[kFinishCap];  // LDS image of (a node sub-range of) the bucket's col segment
+    uint32_t wave_tot[kFinishThreads / kWave];
+};
+
+template <typename Edges>
+__device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int node_shift,
+                                              int64_t N, int64_t *__restrict__ rowptr, int32_t *__restrict__ col, int hub_threshold,
+                                              int32_t *__restrict__ hub_rows, int32_t *__restrict__ hub_count,
+                                              int32_t *__restrict__ mega_rows, int32_t *__restrict__ mega_count)
 {
-    __shared__ uint32_t cnt[1024], excl[1024 + 1];
-    __shared__ int32_t image[kFinishCap];  // LDS image of (a node sub-range of) the bucket's col segment
-    __shared__ uint32_t wave_tot[kFinishThreads / kWave];
+    uint32_t *cnt = lds.cnt, *excl = lds.excl;
     const int nb = 1 << node_shift;  // <= 1024 nodes
     const int64_t node0 = (int64_t)blockIdx.x << node_shift;
-    const unsigned long long seg_lo = fine_base[blockIdx.x], seg_hi = fine_base[blockIdx.x + 1];
-    const uint32_t seg_n = (uint32_t)(seg_hi - seg_lo);
     for (int i = threadIdx.x; i < nb; i += kFinishThreads) cnt[i] = 0;
     __syncthreads();
-    for (uint32_t q0 = 0; q0 < seg_n; q0 += 4 * kFinishThreads) {
-        int y[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t q = q0 + threadIdx.x + k * kFinishThreads;
-            y[k] = q < seg_n ? staged[seg_lo + q].y - (int)node0 : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (y[k] >= 0) atomicAdd(&cnt[y[k]], 1u);
-    }
+    edges.for_each([&](int2 v) { atomicAdd(&cnt[v.y - (int)node0], 1u); });
     __syncthreads();
     {   // exclusive scan of cnt[0..nb): two counters per thread at nb = 1024
         const int per = (nb + kFinishThreads - 1) / kFinishThreads;
@@ -431,10 +496,10 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__re
             const uint32_t o = __shfl_up(inc, off);
             if (lane >= off) inc += o;
         }
-        if (lane == kWave - 1) wave_tot[wv] = inc;
+        if (lane == kWave - 1) lds.wave_tot[wv] = inc;
         __syncthreads();
         uint32_t pre = 0;
-        for (int w = 0; w < wv; ++w) pre += wave_tot[w];
+        for (int w = 0; w < wv; ++w) pre += lds.wave_tot[w];
         uint32_t ex = pre + inc - run;
         for (int k = 0; k < per; ++k) {
             if (b0 + k >= nb) break;
@@ -477,29 +542,167 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__re
         for (int i = n_lo + threadIdx.x; i < n_hi; i += kFinishThreads) cnt[i] = excl[i] - r_lo;  // cursors relative to the range
         __syncthreads();
         if (r_n > 0) {
-            for (uint32_t q0 = 0; q0 < seg_n; q0 += 4 * kFinishThreads) {
-                int2 v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t q = q0 + threadIdx.x + k * kFinishThreads;
-                    v[k] = q < seg_n ? staged[seg_lo + q] : make_int2(0, -1);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int y = v[k].y - (int)node0;
-                    if (v[k].y < 0 || y < n_lo || y >= n_hi) continue;
-                    const uint32_t pos = atomicAdd(&cnt[y], 1u);
-                    if (direct) col[seg_lo + r_lo + pos] = v[k].x;
-                    else image[pos] = v[k].x;
-                }
-            }
+            edges.for_each([&](int2 v) {
+                const int y = v.y - (int)node0;
+                if (y < n_lo || y >= n_hi) return;
+                const uint32_t pos = atomicAdd(&cnt[y], 1u);
+                if (direct) col[seg_lo + r_lo + pos] = v.x;
+                else lds.image[pos] = v.x;
+            });
             __syncthreads();
             if (!direct)
-                for (uint32_t q = threadIdx.x; q < r_n; q += kFinishThreads) col[seg_lo + r_lo + q] = image[q];
+                for (uint32_t q = threadIdx.x; q < r_n; q += kFinishThreads) col[seg_lo + r_lo + q] = lds.image[q];
         }
         __syncthreads();
         n_lo = n_hi;
     }
+}
+
+__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__restrict__ staged, const unsigned long long *__restrict__ fine_base,
+                                                                int node_shift, int64_t N, int64_t *__restrict__ rowptr,
+                                                                int32_t *__restrict__ col, int hub_threshold, int32_t *__restrict__ hub_rows,
+                                                                int32_t *__restrict__ hub_count, int32_t *__restrict__ mega_rows,
+                                                                int32_t *__restrict__ mega_count)
+{
+    __shared__ FinishLds lds;
+    const unsigned long long seg_lo = fine_base[blockIdx.x], seg_hi = fine_base[blockIdx.x + 1];
+    const uint32_t seg_n = (uint32_t)(seg_hi - seg_lo);
+    finish_bucket(ContiguousEdges{staged, seg_lo, seg_n}, lds, seg_lo, seg_n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
+                  mega_rows, mega_count);
+}
+
+// ---- single-pass plan (<= 256 fine buckets, <= kMaxTiles tiles: every shape up to ogbl-collab size) in TWO launches --------
+// tile_sort_kernel: every 4096-edge tile is sorted by bucket in LDS and written back as ONE contiguous tile (no global
+// offsets are needed for that), together with the tile's exclusive bucket offsets off[b][t] (bucket-major, so that a
+// bucket's row is contiguous).  finish_gather_kernel: the workgroup of bucket b reads rows b and b + 1 of `off`:
+//   run of tile t        = staged[t * 4096 + off[b][t] .. off[b+1][t])
+//   start of the bucket  = sum_t off[b][t]      (off[b][t] = edges of tile t with a smaller bucket: their sum over the tiles
+//                                                is the number of edges before bucket b -- no scan kernel, no global counters)
+// and then finishes the bucket like finish_kernel.  Replaces count_keys + scan_block_counts + scan_bases + scatter_tiles +
+// finish (61 us on the bench graph, three of the five launches latency-bound small grids).
+
+__global__ __launch_bounds__(kThreads) void tile_sort_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t E,
+                                                             int64_t N, int shift, int keys, int tiles, int2 *__restrict__ staged,
+                                                             uint32_t *__restrict__ tile_off, unsigned long long *__restrict__ tile_max,
+                                                             int32_t *__restrict__ err, int32_t *__restrict__ hub_count,
+                                                             int32_t *__restrict__ mega_count)
+{
+    __shared__ int2 sorted[kTile];
+    __shared__ uint32_t tile_hist[kMaxKeys], tile_offs[kMaxKeys], wave_tot[kThreads / kWave];
+    __shared__ unsigned long long block_max;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // outputs of the finish launch of this build are cleared here
+        if (hub_count) *hub_count = 0;
+        if (mega_count) mega_count[0] = mega_count[1] = 0;
+    }
+    tile_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) block_max = 0;
+    __syncthreads();
+    constexpr int PER = kTile / kThreads;  // 16 edges per thread
+    const int64_t t0 = (int64_t)blockIdx.x * kTile;
+    const int64_t hi = t0 + kTile < E ? t0 + kTile : E;
+    int64_t my_max = -1;
+    bool bad = false;
+    int2 ed[PER];
+    int key[PER];
+    uint32_t rank[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int64_t e = t0 + threadIdx.x + (int64_t)k * kThreads;
+        key[k] = -1;
+        ed[k] = make_int2(0, 0);
+        if (e < hi) {
+            int64_t s = src[e];
+            const int64_t d = dst[e];
+            const int64_t mx = s > d ? s : d;
+            my_max = mx > my_max ? mx : my_max;
+            if ((uint64_t)d >= (uint64_t)N) { bad = true; continue; }    // out of range: dropped (and reported)
+            if ((uint64_t)s >= (uint64_t)N) { bad = true; s = 0; }       // memory safe; the host raises in strict mode
+            ed[k] = make_int2((int)s, (int)d);
+            key[k] = (int)(d >> shift);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) rank[k] = key[k] >= 0 ? atomicAdd(&tile_hist[key[k]], 1u) : 0u;
+    __syncthreads();
+    uint32_t tile_n = 0;
+    const uint32_t ex = block_exclusive_scan_256(tile_hist[threadIdx.x], wave_tot, &tile_n);
+    tile_offs[threadIdx.x] = ex;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (key[k] >= 0) sorted[tile_offs[key[k]] + rank[k]] = ed[k];
+    if ((int)threadIdx.x < keys) tile_off[(int64_t)threadIdx.x * tiles + blockIdx.x] = ex;
+    if (threadIdx.x == 0) tile_off[(int64_t)keys * tiles + blockIdx.x] = tile_n;
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < tile_n; q += kThreads) staged[t0 + q] = sorted[q];
+    unsigned long long m = my_max < 0 ? 0ULL : (unsigned long long)my_max + 1ULL;
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(&block_max, m);
+    if (bad && err) *err = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_max[blockIdx.x] = block_max;
+}
+
+__global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int2 *__restrict__ staged, const uint32_t *__restrict__ tile_off,
+                                                                       const unsigned long long *__restrict__ tile_max, int tiles, int keys,
+                                                                       int node_shift, int64_t N, int64_t *__restrict__ rowptr,
+                                                                       int32_t *__restrict__ col, unsigned long long *__restrict__ n_self,
+                                                                       int hub_threshold, int32_t *__restrict__ hub_rows,
+                                                                       int32_t *__restrict__ hub_count, int32_t *__restrict__ mega_rows,
+                                                                       int32_t *__restrict__ mega_count)
+{
+    __shared__ FinishLds lds;
+    __shared__ uint32_t seg[kMaxTiles];
+    __shared__ unsigned long long red_base[kFinishThreads / kWave], red_max[kFinishThreads / kWave];
+    __shared__ uint32_t red_n[kFinishThreads / kWave];
+    const uint32_t *row0 = tile_off + (int64_t)blockIdx.x * tiles, *row1 = row0 + tiles;
+    unsigned long long base = 0, mx = 0;
+    uint32_t n = 0;
+    for (int t = threadIdx.x; t < tiles; t += kFinishThreads) {
+        const uint32_t o0 = row0[t], o1 = row1[t];
+        seg[t] = o0 | ((o1 - o0) << 16);
+        base += o0;
+        n += o1 - o0;
+        if (blockIdx.x == 0) {  // the first workgroup also reduces max(edge_index) + 1 (the self-loop count, hashing.py:148)
+            const unsigned long long v = tile_max[t];
+            mx = v > mx ? v : mx;
+        }
+    }
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        base += __shfl_xor(base, off);
+        n += __shfl_xor(n, off);
+        const unsigned long long o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        red_base[threadIdx.x / kWave] = base;
+        red_n[threadIdx.x / kWave] = n;
+        red_max[threadIdx.x / kWave] = mx;
+    }
+    __syncthreads();
+    base = 0, n = 0, mx = 0;
+    for (int w = 0; w < kFinishThreads / kWave; ++w) {
+        base += red_base[w];
+        n += red_n[w];
+        mx = red_max[w] > mx ? red_max[w] : mx;
+    }
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) *n_self = mx;
+        if ((int)blockIdx.x == keys - 1) rowptr[N] = (int64_t)(base + n);  // the last bucket ends the edge list
+    }
+    const uint32_t avg_run = n / (uint32_t)tiles;  // workgroup-uniform
+    if (avg_run < 11)
+        finish_bucket(GatheredEdges<16>{staged, seg, tiles}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
+                      mega_rows, mega_count);
+    else if (avg_run < 22)
+        finish_bucket(GatheredEdges<32>{staged, seg, tiles}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
+                      mega_rows, mega_count);
+    else
+        finish_bucket(GatheredEdges<64>{staged, seg, tiles}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
+                      mega_rows, mega_count);
 }
 
 }  // namespace ss
@@ -536,6 +739,16 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     ProfileSpan span(stream, SS_PROF_CSR);  // all launches of this build
     unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
 
+    if (p.gather) {  // <= 256 fine buckets and <= kMaxTiles tiles: two launches, no counting pass, no scan kernels
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(p.tiles), dim3(kThreads), 0, stream, src, dst, E, N, p.shift1, p.keys1, p.tiles, w.staged_a,
+                           w.tile_off, w.tile_max, err_flag, hub_count, mega_count);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(finish_gather_kernel, dim3((unsigned)p.fine_buckets), dim3(kFinishThreads), 0, stream, w.staged_a, w.tile_off,
+                           w.tile_max, p.tiles, p.keys1, p.node_shift, N, rowptr, col, n_self, (int)hub_threshold, hub_rows, hub_count,
+                           mega_rows, mega_count);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+    }
     // ---- pass 1 ----
     PassArgs a1 = {};
     a1.src = src; a1.dst = dst; a1.E = E; a1.N = N; a1.slice = p.slice1; a1.shift = p.shift1; a1.keys = p.keys1;

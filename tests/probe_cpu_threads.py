@@ -4,7 +4,7 @@ import numpy as np, torch
 import bench
 import subgraph_sketching_amd as ssa
 from oracle import oracle, torch_refstyle as tr
-ei = bench.synthetic_graph(); links = bench.synthetic_links(2)
+ei = bench.synthetic_graph(); links = bench.synthetic_links(seed=2)
 t = ssa.hll_tables.load(8)
 raw, bias = torch.tensor(t.raw_estimate, dtype=torch.float), torch.tensor(t.bias, dtype=torch.float)
 mh0 = torch.from_numpy(oracle.minhash_init(bench.N_NODES, 128).astype(np.int64)); hll0 = torch.from_numpy(oracle.hll_init(bench.N_NODES, 8).view(np.int8))

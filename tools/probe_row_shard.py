@@ -9,10 +9,9 @@ import subgraph_sketching_amd as ssa
 from argparse import Namespace
 cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else 'ppa']
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-bench.N_NODES, bench.E_UND, bench.H, bench.BATCH = cfg['n'], cfg['e_und'], cfg['h'], cfg['batch']
 dev = torch.device('cuda:0')
-n, h = bench.N_NODES, bench.H
-ei = torch.from_numpy(bench.synthetic_graph()).to(dev)
+n, h = cfg['n'], cfg['h']
+ei = torch.from_numpy(bench.synthetic_graph(cfg['n'], cfg['e_und'])).to(dev)
 eh = ssa.ElphHashes(Namespace(max_hash_hops=h, hll_p=8, minhash_num_perm=128, floor_sf=False, use_zero_one=True))
 eh.strict_bounds = False
 per = (n + G - 1) // G
@@ -39,7 +38,7 @@ def timed(fn, reps=5):
 
 
 full = timed(lambda: eh.build_hash_tables(n, ei))
-print(f'N={n} E_dir={2 * bench.E_UND} h={h}: unsharded build {full:.3f} ms', flush=True)
+print(f'N={n} E_dir={2 * cfg['e_und']} h={h}: unsharded build {full:.3f} ms', flush=True)
 for r in (0, G // 2, G - 1):
     t = timed(lambda: eh._build(n, ei, Shard(r)))
     print(f'rank {r} of {G}: CSR (replicated) + own rows of {h} hops {t:.3f} ms', flush=True)
