@@ -13,6 +13,8 @@
 // inside the row with DPP (quad_perm / row_half_mirror / row_mirror -- no LDS traffic), then lane c < h^2
 // runs the HLL++ estimator for combination c and the h(h+2) features are assembled in fp32 in the
 // reference's own operation order.
+#include <cstdlib>
+
 #include "ss_common.hpp"
 
 namespace ss {
@@ -135,7 +137,10 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
                                                             const float *__restrict__ degrees)
 {
     __shared__ EstimatorLds lds;
-    const EstimatorTables est = stage_tables(lds, prm);
+    // the estimator tables are staged into LDS AFTER the first pair's sketch rows have been requested (first loop iteration
+    // below): their 2.6 KB come out of the L2 while the 12 KiB of rows per wavefront travel, instead of 2 us before them
+    EstimatorTables est = {};
+    bool staged = false;
 
     constexpr int NF = H * (H + 2);
     constexpr int NC = H * H;
@@ -186,6 +191,22 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
             u_next = links[2 * (q_raw + stride)];
             v_next = links[2 * (q_raw + stride) + 1];
         }
+        if (!staged) {  // workgroup-uniform (the trip count is): the barrier inside is reached by every thread
+            est = stage_tables(lds, prm);
+            staged = true;
+        }
+        // MinHash first: the equality counts consume (and free) the 2H MinHash rows before the HLL rows are expanded into their
+        // digests (120 -> 113 VGPRs at H = 2, 166 -> 147 at H = 3)
+        int match[NC];
+#pragma unroll
+        for (int k1 = 0; k1 < H; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < H; ++k2) {
+                int m = 0;
+#pragma unroll
+                for (int c = 0; c < CMPL; ++c) m += eq4(mu[k1][c], mv[k2][c]);
+                match[k1 * H + k2] = m;
+            }
         HllChunk hu[H][CHPL], hv[H][CHPL];
 #pragma unroll
         for (int k = 0; k < H; ++k)
@@ -198,19 +219,21 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
         for (int k1 = 0; k1 < H; ++k1)
 #pragma unroll
             for (int k2 = 0; k2 < H; ++k2) {
-                int match = 0, zeros = 0;
+                int zeros = 0;
                 float hsum = 0.0f;
 #pragma unroll
-                for (int c = 0; c < CMPL; ++c) match += eq4(mu[k1][c], mv[k2][c]);
-#pragma unroll
                 for (int c = 0; c < CHPL; ++c) union_stats_digested(hu[k1][c], hv[k2][c], zeros, hsum);
-                mz[k1 * H + k2] = row16_sum_i((match << 20) | zeros);
+                mz[k1 * H + k2] = row16_sum_i((match[k1 * H + k2] << 20) | zeros);
                 hs[k1 * H + k2] = row16_sum_f(hsum);
             }
     } else {
         if (q_raw + stride < B) {
             u_next = links[2 * (q_raw + stride)];
             v_next = links[2 * (q_raw + stride) + 1];
+        }
+        if (!staged) {
+            est = stage_tables(lds, prm);
+            staged = true;
         }
         const int CM = P >> 2, CH = M >> 4;
 #pragma unroll
@@ -293,11 +316,19 @@ int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &t
                  int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream)
 {
     const int pairs_per_block = 256 / kRow;
-    // at least two pairs per lane group when there are enough of them (the second one's ids travel under the first one's
-    // rows), at most kPairGrid workgroups: measured at h = 2, B = 65 536: 36.5 us with 2 048 workgroups, 38.0 with 4 096;
-    // B = 4 M: 2.23 G pairs/s with 8 192 workgroups, 2.18 with 2 048, 2.06 with 1 280
-    int64_t blocks = (B + 2 * pairs_per_block - 1) / (2 * pairs_per_block);
-    if (blocks > kPairGrid) blocks = kPairGrid;
+    // pairs per 16-lane group the grid is sized for: ONE while that still fits the chip in a single round of workgroups (ELPH
+    // batches: B = 2 048 takes 5.4 us instead of 8.2), TWO beyond (the second pair's ids travel under the first one's rows:
+    // B = 65 536: 35.6 us with 2 048 workgroups, 39.0 with 4 096), at most kPairGrid workgroups (B = 4 M: 2.23 G pairs/s with
+    // 8 192, 2.18 with 2 048, 2.06 with 1 280).  Measured and rejected: 64- / 128-thread workgroups, persistent
+    // grids of 512 - 1 024 workgroups, and a software-pipelined variant that requests the next pair's rows in the middle of the
+    // current pair's arithmetic (165 VGPRs: +1.5 % on batches of millions, -7 % at B = 65 536).
+    // SS_PAIR_GRID / SS_PAIR_PER_GROUP: tuning hooks of tools/probe_pairs.py
+    static const int grid_env = getenv("SS_PAIR_GRID") ? atoi(getenv("SS_PAIR_GRID")) : 0;
+    static const int per_group_env = getenv("SS_PAIR_PER_GROUP") ? atoi(getenv("SS_PAIR_PER_GROUP")) : 0;
+    const int per_group = per_group_env > 0 ? per_group_env : (B <= 1024 * pairs_per_block ? 1 : 2);
+    const int64_t max_blocks = grid_env > 0 ? grid_env : kPairGrid;
+    int64_t blocks = (B + per_group * pairs_per_block - 1) / (per_group * pairs_per_block);
+    if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     {
         ProfileSpan span(stream, SS_PROF_PAIRS);

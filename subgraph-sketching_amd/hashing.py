@@ -846,7 +846,7 @@ class ElphHashes(object):
                 raise ValueError('hash tables of different hops must have the same shape')
         return mh, hll, N, P
 
-    def _pair_kernel(self, links, hash_table, cards, want_debug=False, degrees=None):
+    def _pair_kernel(self, links, hash_table, cards, want_debug=False, degrees=None, floor_sf=None):
         """runs ss_pair_features for links [B,2]; returns (features [B,nf] (or [B,2nf] with degrees) on device, debug dict or None)"""
         # where the links live, else where the packed tables already are, else cards, else the current device
         first = hash_table.get(1) if hasattr(hash_table, 'get') else None
@@ -880,7 +880,8 @@ class ElphHashes(object):
         nf = h * (h + 2)
         mh_ptrs = (c_void_p * h)(*[t.data_ptr() for t in mh])
         hll_ptrs = (c_void_p * h)(*[t.data_ptr() for t in hll])
-        flags = (_native.SS_FLAG_USE_ZERO_ONE if self.use_zero_one else 0) | (_native.SS_FLAG_FLOOR_SF if self.floor_sf else 0)
+        floor = self.floor_sf if floor_sf is None else floor_sf  # DeviceFeatureStore records HashDataset's post-hoc floor
+        flags = (_native.SS_FLAG_USE_ZERO_ONE if self.use_zero_one else 0) | (_native.SS_FLAG_FLOOR_SF if floor else 0)
         err = _error_flag(device) if self.strict_bounds else None  # non-strict launches never touch the shared flag
         if degrees is not None:
             dg = degrees.to(device=device, dtype=torch.float32).contiguous()
@@ -981,7 +982,7 @@ class ElphHashes(object):
             raise ValueError('source and destination hash value shapes must be the same')
         return torch.count_nonzero(src == dst, dim=-1) / self.num_perm
 
-    def get_subgraph_features(self, links, hash_table, cards, batch_size=11000000, degrees=None):
+    def get_subgraph_features(self, links, hash_table, cards, batch_size=11000000, degrees=None, lazy=False):
         """structural features of node pairs: approximations of the number of nodes at distance (d_u, d_v)
         from (u, v), for the (d_u, d_v) listed in LABEL_LOOKUP[max_hops] (reference :258-323).
         @param links: int tensor [n_edges, 2] (or [2])
@@ -991,11 +992,16 @@ class ElphHashes(object):
         @param degrees: optional float tensor [N] (HashDataset.degrees, datasets/elph.py:74).  Extension beyond the
                reference signature: when given, BUDDY's degree-normalised copy (models/elph.py:276-293: feature /
                sqrt(d_u * d_v), NaN / Inf -> 0) is appended in the same kernel and the result is [n_edges, 2 * F].
+        @param lazy: extension: return a `DeviceFeatureStore` (feature_store.py) instead of the tensor -- rows are computed on
+               the GPU when a batch indexes it (runners/train.py:58-60), nothing of size [n_edges, F] is materialised
         @return: float32 [n_edges, max_hops * (max_hops + 2)] on links.device"""
         if self.max_hops not in (1, 2, 3):
             raise NotImplementedError("Only 1, 2 and 3 hop hashes are implemented")
         if links.dim() == 1:
             links = links.unsqueeze(0)
+        if lazy:
+            from .feature_store import DeviceFeatureStore
+            return DeviceFeatureStore(self, links, hash_table, cards, degrees=degrees, batch_size=batch_size)
         n = links.size(0)
         if n <= batch_size:
             feats, _ = self._pair_kernel(links, hash_table, cards, degrees=degrees)
