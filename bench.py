@@ -111,14 +111,13 @@ def cpu_baseline_reference_style(ei, links, n, h, batch):
     scatter-amax, int64 MinHash, h^2 x 4 row gathers, argsort-based bias lookup.  One full step (all h hops + the query of
     one batch) is timed.  Calibration against the real (shimmed) reference: profiles/round2_cpu_baseline_calibration.json."""
     import subgraph_sketching_amd as ssa
-    from oracle import oracle, torch_refstyle as tr
+    from oracle import torch_refstyle as tr
     t = ssa.hll_tables.load(HLL_P)
     raw, bias = torch.tensor(t.raw_estimate, dtype=torch.float), torch.tensor(t.bias, dtype=torch.float)
     threads = min(16, os.cpu_count())  # measured best on the 256-core GPU host (8: 3.5 s/hop, 16: 2.5, 32: 3.0, 128: 6.0)
     torch.set_num_threads(threads)
-    mh0 = torch.from_numpy(oracle.minhash_init(n, P).astype(np.int64))
-    hll0 = torch.from_numpy(oracle.hll_init(n, HLL_P).view(np.int8))
     t0 = time.perf_counter()
+    mh0, hll0 = tr.init_sketches(n, P, HLL_P)  # the reference makes the hop-0 sketches on the host inside its build (hashing.py:157-158)
     tables, cards = tr.build_tables(n, torch.from_numpy(ei), h, mh0, hll0, HLL_P, t.alpha, t.threshold, raw, bias, hops_to_run=h)
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()

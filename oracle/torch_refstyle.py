@@ -16,6 +16,31 @@ import numpy as np
 import torch
 
 
+def init_sketches(num_nodes, num_perm, p, seed=1):
+    """hop-0 sketches the way the reference makes them on the host (hashing.py:106-137): pandas' hash_array of the ids 1..N,
+    one broadcast numpy expression over [N, P] uint64 for the permuted hashes (with the int64 ones-matrix and the minimum
+    the reference applies), numpy scatter for the HLL registers, then torch.tensor copies.  Part of the reference's build
+    time (3.9 s of 13.3 s at ogbl-collab size on 8 cores), so the reference-style baseline times it too."""
+    from pandas.util import hash_array
+    prime, max_hash = np.uint64((1 << 61) - 1), np.uint64((1 << 32) - 1)
+    gen = np.random.RandomState(seed)
+    ab = np.array([(gen.randint(1, prime, dtype=np.uint64), gen.randint(0, prime, dtype=np.uint64)) for _ in range(num_perm)],
+                  dtype=np.uint64).T
+    ceiling = np.ones((num_nodes, num_perm), dtype=np.int64) * max_hash
+    hv = hash_array(np.arange(1, num_nodes + 1))
+    permuted = np.bitwise_and((ab[0] * np.expand_dims(hv, 1) + ab[1]) % prime, max_hash)
+    mh0 = torch.tensor(np.minimum(permuted, ceiling), dtype=torch.int64)
+    m = 1 << p
+    regs = np.zeros((num_nodes, m), dtype=np.int8)
+    hv = hash_array(np.arange(1, num_nodes + 1))
+    bits = hv >> np.uint64(p)
+    rank = (64 - p) - np.ceil(np.log2(bits.astype(np.float64) + 1.0)).astype(np.int64) + 1   # reference :83-104 (float bit length)
+    rows = np.arange(num_nodes)
+    idx = (hv & np.uint64(m - 1)).astype(np.int64)
+    regs[rows, idx] = np.maximum(regs[rows, idx], rank)
+    return mh0, torch.tensor(regs, dtype=torch.int8)
+
+
 def scatter_max_propagate(x, src, dst):
     """out[i] = max over edges (j -> i) of x[j]; rows without an in-edge are 0"""
     out = torch.zeros_like(x)
@@ -32,10 +57,9 @@ def cardinality(regs, p, alpha, threshold, raw_estimate, bias):
     out[has_zero] = m * torch.log(m / zeros[has_zero])
     use_raw = out > threshold
     e = (alpha * m ** 2) / torch.sum(2.0 ** (-regs[use_raw]), dim=1)
-    nearest = torch.argsort((e.unsqueeze(-1) - raw_estimate) ** 2)[:, :6]
-    corr = torch.mean(bias[nearest], dim=1)
-    small = e <= 5 * m
-    e[small] = e[small] - corr[small]
+    small = e <= 5 * m  # only these estimates go through the bias lookup (hashing.py:206-210)
+    nearest = torch.argsort((e[small].unsqueeze(-1) - raw_estimate) ** 2)[:, :6]
+    e[small] = e[small] - torch.mean(bias[nearest], dim=1)
     out[use_raw] = e
     return out
 
