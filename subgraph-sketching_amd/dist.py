@@ -9,6 +9,8 @@ the per-rank feature rows -- one all_gather_into_tensor of [ceil(L/G), h(h+2)] f
 min/max and integer counts are order independent, so every rank's replicated table is bit-identical
 and no reduction collective exists on the path.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -41,6 +43,23 @@ def sharded_subgraph_features(compute, links, group=None):
     return gathered[:L]
 
 
+def exchange_blocks_p2p(full, rank, world, per, group=None):
+    """the all-gather of equally sized blocks (`per` leading rows / elements each, block r owned by rank r, in place in `full`)
+    as world - 1 concurrent point-to-point transfers per rank: one send of the own block to every peer, one receive from
+    every peer, all posted at once (batch_isend_irecv) -- on xGMI each lands on its own link.  Returns the request list
+    (wait on all of them); synchronous backends (gloo on CPU tensors) complete before returning."""
+    ops = []
+    mine = full[rank * per:(rank + 1) * per]
+    for step in range(1, world):
+        dst, src = (rank + step) % world, (rank - step) % world
+        ops.append(dist.P2POp(dist.isend, mine, dst, group))
+        ops.append(dist.P2POp(dist.irecv, full[src * per:(src + 1) * per], src, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    for r in reqs:
+        r.wait()
+    return reqs
+
+
 class RowShard(object):
     """destination-row partition of one build across the ranks of `group` + the exchange that follows every hop.
 
@@ -59,6 +78,9 @@ class RowShard(object):
         lo = min(self.rank * self.per, num_nodes)
         self.rows = (lo, min(lo + self.per, num_nodes))
         self.native = dist.get_backend(group) == 'nccl'
+        # SS_EXCHANGE=p2p: G - 1 concurrent point-to-point transfers per rank instead of one all_gather (tools/probe_allgather.py
+        # decides which is faster on a given node: a ring all-gather is bound by one xGMI link)
+        self.p2p = os.environ.get('SS_EXCHANGE', 'all_gather') == 'p2p'
 
     def block(self, full):
         return full[self.rank * self.per:(self.rank + 1) * self.per]
@@ -66,6 +88,9 @@ class RowShard(object):
     def gather(self, full):
         """every rank's owned block of `full` ([padded_rows, ...], contiguous) reaches every other rank"""
         assert full.size(0) == self.padded_rows and full.is_contiguous()
+        if self.p2p and (self.native or not full.is_cuda):
+            exchange_blocks_p2p(full, self.rank, self.world, self.per, self.group)  # stream-ordered on RCCL; blocking on gloo
+            return None
         if self.native or not full.is_cuda:
             mine = self.block(full) if self.native else self.block(full).clone()  # RCCL gathers in place
             return dist.all_gather_into_tensor(full, mine, group=self.group, async_op=self.native)

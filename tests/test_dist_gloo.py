@@ -58,8 +58,9 @@ def test_sharded_query_world2(tmp_path, L):
 
 
 # ---- sharded build: destination rows partitioned, in-place all-gather after every hop ------------------
-def _build_worker(rank, world, port, n, out_dir):
+def _build_worker(rank, world, port, n, out_dir, exchange='all_gather'):
     import sys
+    os.environ['SS_EXCHANGE'] = exchange  # all_gather_into_tensor, or G - 1 concurrent point-to-point transfers per rank
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -73,6 +74,7 @@ def _build_worker(rank, world, port, n, out_dir):
     ei = np.concatenate([e, e[::-1]], axis=1)
     ei_loops = oracle.add_self_loops(ei)
     shard = ssa.dist.RowShard(n, None)
+    assert shard.p2p == (exchange == 'p2p')
     lo, hi = shard.rows
     assert shard.padded_rows % world == 0 and shard.padded_rows >= n and 0 <= lo <= hi <= n
     if world == 2 and n > 2:
@@ -104,10 +106,11 @@ def _build_worker(rank, world, port, n, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('exchange', ['all_gather', 'p2p'])
 @pytest.mark.parametrize('n', [501, 64, 1])
-def test_sharded_build_protocol_world2(tmp_path, n):
+def test_sharded_build_protocol_world2(tmp_path, n, exchange):
     world = 2
-    mp.spawn(_build_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_build_worker, args=(world, _free_port(), n, str(tmp_path), exchange), nprocs=world, join=True)
     a, b = torch.load(tmp_path / 'build_rank0.pt'), torch.load(tmp_path / 'build_rank1.pt')
     assert all(torch.equal(x, y) for x, y in zip(a, b))
 
@@ -169,3 +172,23 @@ def test_batch_plan_and_async_gather_world2(tmp_path, batch):
     mp.spawn(_plan_worker, args=(world, _free_port(), batch, str(tmp_path)), nprocs=world, join=True)
     a, b = torch.load(tmp_path / 'plan_rank0.pt'), torch.load(tmp_path / 'plan_rank1.pt')
     assert torch.equal(a['strong'], b['strong']) and torch.equal(a['weak'], b['weak'])
+
+
+def _p2p_worker(rank, world, port, per):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import subgraph_sketching_amd as ssa
+    full = torch.full((world * per, 3), -1, dtype=torch.int32)
+    full[rank * per:(rank + 1) * per] = rank + 10
+    ssa.dist.exchange_blocks_p2p(full, rank, world, per)
+    want = torch.arange(world, dtype=torch.int32).repeat_interleave(per)[:, None].expand(-1, 3) + 10
+    assert torch.equal(full, want), f'rank {rank}: blocks after the point-to-point exchange differ'
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,per', [(3, 7), (4, 1), (2, 100)])
+def test_point_to_point_block_exchange(world, per):
+    """the direct (link-parallel) form of the per-hop exchange: every rank ends with every block, any world size"""
+    mp.spawn(_p2p_worker, args=(world, _free_port(), per), nprocs=world, join=True)
