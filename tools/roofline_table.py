@@ -18,7 +18,8 @@ import bench  # noqa: E402  (CONFIGS only)
 import subgraph_sketching_amd as ssa  # noqa: E402
 
 FAMILIES = [('propagate_kernel<128, 256>', 'minhash_hop'), ('hll_propagate_row16_kernel', 'hll_hop'),
-            ('first_hop_kernel<2, true, false>', 'first_hop_minhash'), ('hll_first_hop_kernel', 'first_hop_hll'),
+            ('first_hop_kernel<2, true, false>', 'first_hop_minhash'), ('first_hop_rows_kernel<2', 'first_hop_minhash'),
+            ('hll_first_hop_kernel', 'first_hop_hll'),
             ('pair_features_kernel', 'pair_features')]
 
 
