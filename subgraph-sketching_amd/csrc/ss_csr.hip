@@ -427,16 +427,27 @@ struct ContiguousEdges {
 
 // LANES lanes read one tile's run; chosen from the average run length of the bucket (tile / buckets = ~18 edges on the bench
 // graph -> 32 lanes; skewed buckets whose runs are hundreds of edges -> whole wavefronts), so that most runs need one load
+constexpr int kLongRun = 256;   // runs above this many edges (a SORTED stretch of the edge list -- e.g. the self loops ELPH
+constexpr int kLongCap = 128;   // appends, models/elph.py:186 -- puts a whole bucket into one tile) are walked by the whole workgroup
 template <int LANES>
 struct GatheredEdges {
     const int2 *staged;
     const uint32_t *seg;  // LDS [tiles]: run start inside the tile (low 16 bits) | run length << 16
     int tiles;
+    const uint16_t *long_tiles;  // LDS: tiles whose run is longer than kLongRun (listed by the kernel prologue) ...
+    int n_long;                  // ... or 0 when there are none / too many to list (then every run is walked by its lane group)
     template <typename F>
     __device__ __forceinline__ void for_each(F &&f) const
     {
         constexpr int kGroups = kFinishThreads / LANES;
         const int grp = threadIdx.x / LANES, l = threadIdx.x % LANES;
+        const uint32_t skip_above = n_long ? (uint32_t)kLongRun : 0xFFFFFFFFu;
+        for (int k = 0; k < n_long; ++k) {  // long runs: all threads, coalesced
+            const int t = long_tiles[k];
+            const uint32_t d = seg[t];
+            const int2 *run = staged + (int64_t)t * kTile + (d & 0xFFFFu);
+            for (uint32_t q = threadIdx.x; q < (d >> 16); q += kFinishThreads) f(run[q]);
+        }
         for (int t0 = grp; t0 < tiles; t0 += 4 * kGroups) {  // four runs requested per lane group before the first is consumed
             int2 v[4];
             uint32_t len[4];
@@ -444,7 +455,7 @@ struct GatheredEdges {
             for (int k = 0; k < 4; ++k) {
                 const int t = t0 + k * kGroups;
                 const uint32_t d = t < tiles ? seg[t] : 0u;
-                len[k] = d >> 16;
+                len[k] = (d >> 16) > skip_above ? 0u : d >> 16;
                 v[k] = (uint32_t)l < len[k] ? staged[(int64_t)t * kTile + (d & 0xFFFFu) + l] : make_int2(0, -1);
             }
 #pragma unroll
@@ -656,14 +667,22 @@ __global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int
 {
     __shared__ FinishLds lds;
     __shared__ uint32_t seg[kMaxTiles];
+    __shared__ uint16_t long_tiles[kLongCap];
+    __shared__ int n_long_s;
     __shared__ unsigned long long red_base[kFinishThreads / kWave], red_max[kFinishThreads / kWave];
     __shared__ uint32_t red_n[kFinishThreads / kWave];
     const uint32_t *row0 = tile_off + (int64_t)blockIdx.x * tiles, *row1 = row0 + tiles;
     unsigned long long base = 0, mx = 0;
     uint32_t n = 0;
+    if (threadIdx.x == 0) n_long_s = 0;
+    __syncthreads();
     for (int t = threadIdx.x; t < tiles; t += kFinishThreads) {
         const uint32_t o0 = row0[t], o1 = row1[t];
         seg[t] = o0 | ((o1 - o0) << 16);
+        if (o1 - o0 > (uint32_t)kLongRun) {
+            const int k = atomicAdd(&n_long_s, 1);
+            if (k < kLongCap) long_tiles[k] = (uint16_t)t;
+        }
         base += o0;
         n += o1 - o0;
         if (blockIdx.x == 0) {  // the first workgroup also reduces max(edge_index) + 1 (the self-loop count, hashing.py:148)
@@ -694,14 +713,15 @@ __global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int
         if ((int)blockIdx.x == keys - 1) rowptr[N] = (int64_t)(base + n);  // the last bucket ends the edge list
     }
     const uint32_t avg_run = n / (uint32_t)tiles;  // workgroup-uniform
+    const int n_long = n_long_s <= kLongCap ? n_long_s : 0;  // (red_* were written behind a barrier: n_long_s is final here)
     if (avg_run < 11)
-        finish_bucket(GatheredEdges<16>{staged, seg, tiles}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
+        finish_bucket(GatheredEdges<16>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
                       mega_rows, mega_count);
     else if (avg_run < 22)
-        finish_bucket(GatheredEdges<32>{staged, seg, tiles}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
+        finish_bucket(GatheredEdges<32>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
                       mega_rows, mega_count);
     else
-        finish_bucket(GatheredEdges<64>{staged, seg, tiles}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
+        finish_bucket(GatheredEdges<64>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
                       mega_rows, mega_count);
 }
 
