@@ -286,7 +286,7 @@ def main():
     kernel_table = None
     if not a.no_kernel_table:
         tags = {'csr_build': nat.PROF_CSR, 'first_hop_hll': nat.PROF_FIRST_HOP_HLL, 'first_hop_minhash': nat.PROF_FIRST_HOP_MH,
-                'hll_hop': nat.PROF_HLL_HOP, 'minhash_hop': nat.PROF_MINHASH_HOP, 'hub_passes': nat.PROF_HUB,
+                'hll_hop': nat.PROF_HLL_HOP, 'fused_first_hop_hll_hop': nat.PROF_FUSED, 'minhash_hop': nat.PROF_MINHASH_HOP, 'hub_passes': nat.PROF_HUB,
                 'pair_features': nat.PROF_PAIRS}
         lib.ss_profile_enable(sum(1 << t for t in tags.values()))
         extra = 5

@@ -112,134 +112,17 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
 //   * and then walks row after row over its slice of the batch (two-phase evaluation of ss_walks.hpp: phase 1 finds which
 //     neighbour attains the minimum, phase 2 evaluates that one exactly).
 // Rows flagged ambiguous (and rows that list themselves: duplicates of the implicit self loop) are redone by the exact walk.
+// (The walk itself is MinhashRows of ss_walks.hpp, shared with the fused kernel of ss_fused_hop.hip.)
 constexpr int kRowsPerWave = 8;
 
 template <int PPL, int R>
 __global__ __launch_bounds__(256) void first_hop_rows_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
                                                              uint32_t *__restrict__ mh_out, int p, bool skip_hubs)
 {
-    constexpr int P = PPL * kWave;
-    constexpr int kNb = kWave - R;  // col entries per batch; lanes kNb .. 63 carry the self-loop hashes
-    const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t i0 = g.row0 + ((int64_t)blockIdx.x * (blockDim.x / kWave) + wave) * R;
-    if (i0 >= g.row1) return;
-    const int rows = (int)(g.row1 - i0 < R ? g.row1 - i0 : R);
-    // bounds of all rows with one load: lane l holds rowptr[i0 + l] (l <= rows), as an offset from the first row's start
-    const int64_t rp = lane <= rows ? g.rowptr[i0 + lane] : 0;
-    const int64_t c_lo = ((int64_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)rp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)rp);
-    const int rel = (int)(rp - c_lo);
-    const int c_n = __builtin_amdgcn_readlane(rel, rows);  // col entries of the whole chunk
-    const int32_t *nb = g.col + c_lo;
-    uint64_t a[PPL], b[PPL];
-    uint32_t a_lo[PPL], b8[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-        a[q] = pa[lane + kWave * q];
-        b[q] = pb[lane + kWave * q];
-        a_lo[q] = (uint32_t)a[q];
-        b8[q] = (uint32_t)b[q] + 8u;
-    }
-    const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
-
-    int base = 0;  // chunk-relative position of the current batch's first col entry
-    int64_t nid = 0;
-    uint32_t hv_lo = 0, hv_hi = 0;
-    auto load_batch = [&]() {
-        const int t = base + lane;
-        nid = lane >= kNb ? i0 + (lane - kNb) : (t < c_n ? (int64_t)nb[t] : 0);
-        const uint64_t hv = hash_u64((uint64_t)(nid + 1));
-        hv_lo = (uint32_t)hv;
-        hv_hi = (uint32_t)(hv >> 32);
-    };
-    load_batch();
-
-    for (int r = 0; r < rows; ++r) {  // wave-uniform
-        const int64_t i = i0 + r;
-        const int p0 = __builtin_amdgcn_readlane(rel, r), p1 = __builtin_amdgcn_readlane(rel, r + 1);
-        const int deg = p1 - p0;
-        if (skip_hubs && deg > g.hub_threshold) continue;  // left to first_hop_hub_kernel
-        const bool self = i < n_self;
-        uint32_t acc[PPL];
-        bool redo = false;
-        if (deg + (self ? 1 : 0) == 0) {
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) acc[q] = 0u;  // no in-edge, no self loop: all-zero row (PyG default)
-        } else {
-            uint32_t m1[PPL], m2[PPL], h1_lo[PPL], h1_hi[PPL];
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) {
-                m1[q] = m2[q] = 0xFFFFFFFFu;
-                h1_lo[q] = h1_hi[q] = 0u;
-            }
-            auto update = [&](uint32_t h_lo, uint32_t slot) {
-#pragma unroll
-                for (int q = 0; q < PPL; ++q) {
-                    const uint32_t x = a_lo[q] * h_lo + b8[q];
-                    uint32_t key;
-                    asm("v_bfi_b32 %0, 63, %1, %2" : "=v"(key) : "s"(slot), "v"(x));  // (x & ~63) | slot, see ss_walks.hpp
-                    m2[q] = umed3(m1[q], m2[q], key);
-                    m1[q] = key < m1[q] ? key : m1[q];
-                }
-            };
-            int pos = p0;
-            bool seen_self = false;
-            for (;;) {
-                if (pos < p1 && pos >= base + kNb) {  // the row starts (or continues) beyond the current batch
-                    base += (pos - base) / kNb * kNb;  // (a skipped hub row may lie in between: jump, do not step)
-                    load_batch();
-                }
-                const int s_lo = pos - base;
-                const int s_hi = p1 - base < kNb ? p1 - base : kNb;
-                uint32_t before[PPL];
-#pragma unroll
-                for (int q = 0; q < PPL; ++q) before[q] = m1[q];
-                // a row that lists itself would meet its implicit self loop as a duplicate (ambiguous for every permutation)
-                seen_self |= __any(lane >= s_lo && lane < s_hi && nid == i);
-                int k = s_lo;
-                for (; k + 3 < s_hi; k += 4) {
-                    uint32_t hl[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) hl[u] = (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k + u);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) update(hl[u], (uint32_t)(k + u));
-                }
-                for (; k < s_hi; ++k) update((uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k), (uint32_t)k);
-                pos = base + (s_hi > s_lo ? s_hi : s_lo);
-                const bool last = pos >= p1;
-                if (last && self && !seen_self) update((uint32_t)__builtin_amdgcn_readlane((int)hv_lo, kNb + r), (uint32_t)(kNb + r));
-                // the batch's hashes still sit one per lane: fetch the one whose slot now holds the smallest key
-#pragma unroll
-                for (int q = 0; q < PPL; ++q) {
-                    const int slot = (int)(m1[q] & 63u);
-                    const uint32_t cand_lo = (uint32_t)__shfl((int)hv_lo, slot), cand_hi = (uint32_t)__shfl((int)hv_hi, slot);
-                    const bool changed = m1[q] != before[q];
-                    h1_lo[q] = changed ? cand_lo : h1_lo[q];
-                    h1_hi[q] = changed ? cand_hi : h1_hi[q];
-                }
-                if (last) break;
-            }
-            bool ambiguous = false;
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) {
-                // x = a * h + b (mod 2^64); the permuted hash is x mod (2^61 - 1) = (x & M) + (x >> 61) [- M], whose low word
-                // is lo32(x) + (x >> 61) unless the sum reaches M -- only possible when bits 32..60 of x are all ones: such
-                // a row (2^-29 per evaluation) is flagged and redone exactly like the key collisions
-                const uint64_t lo = (uint64_t)a_lo[q] * h1_lo[q] + b[q];
-                const uint32_t hi = (uint32_t)(lo >> 32) + a_lo[q] * h1_hi[q] + (uint32_t)(a[q] >> 32) * h1_lo[q];
-                acc[q] = (uint32_t)lo + (hi >> 29);
-                ambiguous |= ((hi & 0x1FFFFFFFu) == 0x1FFFFFFFu) | (m1[q] < 64u) | ((m2[q] >> 6) - (m1[q] >> 6) <= 1u);
-            }
-            redo = __any(ambiguous);
-        }
-        if (redo) {
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
-            first_hop_walk<PPL, true, false>(nb + p0, deg, deg + (self ? 1 : 0), i, 0, 1, p, a, b, acc, nullptr, lane);
-        }
-#pragma unroll
-        for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = acc[q];
-    }
+    MinhashRows<PPL, R> m;
+    if (!m.init(g, g.row0 + ((int64_t)blockIdx.x * (blockDim.x / kWave) + wave) * R, pa, pb, p, skip_hubs)) return;
+    for (int r = 0; r < m.rows; ++r) m.row(r, mh_out);  // wave-uniform
 }
 
 // HLL-only first hop, latency-optimised: one 16-lane DPP row per destination (4 destinations in flight per wave).

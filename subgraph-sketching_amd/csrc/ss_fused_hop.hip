@@ -1,0 +1,247 @@
+// ss_fused_hop.hip -- the MinHash first hop and the HLL table hop of hop 2 in ONE launch, interleaved inside every wavefront.
+//
+// Why: of the kernels of a build the MinHash first hop (hop 1 recomputed from node ids, ss_first_hop.hip) is bound by VALU issue
+// (VALUBusy 88 %) and the HLL table hop (ss_propagate.hip) by memory (VALUBusy 47 %); they use different pipes but as separate
+// kernels they cannot overlap -- on two streams they share the wave slots and each runs at half rate (both are latency-bound by
+// occupancy; tools/probe_overlap.py: 385 us against 392 us back to back).  Inside one wavefront they can: the wave POSTS the HLL
+// row loads of four of its rows, walks the MinHash first hop of those rows while the loads travel, and only then folds the HLL
+// rows -- the memory pipe works under the VALU pipe.
+//
+// Data dependencies make this the only such pair of a build: hop-2 HLL rows need the COMPLETE hop-1 HLL table (so the HLL first
+// hop and its hub pass run before this launch); hop-1 MinHash rows need nothing but the graph.  A build of h >= 2 hops is
+//     ss_first_hop (HLL only: hop-1 HLL + cards)  ->  ss_fused_hop_stage [this file]  ->  ss_propagate for hops 3..h
+// where ss_fused_hop_stage = this kernel, the hub pass of the hop-1 MinHash rows, the MinHash table hop of hop 2
+// (propagate_kernel<128,256>) and ONE hub pass for both hop-2 sketches: one hub launch more than the unfused schedule.
+// Results are bit-identical to the unfused sequence: the MinHash side is MinhashRows (ss_walks.hpp, shared with
+// first_hop_rows_kernel), the HLL side folds the same rows with the same byte-wise max and runs the same cardinality epilogue.
+//
+// Mapping: a wavefront owns kFusedRows = 4 consecutive destination rows.  MinHash side: as first_hop_rows_kernel (with 4 rows the
+// 60 col entries of a batch almost always cover the whole chunk: a batch reload in the middle of the walk would have to wait for
+// its ids with vmcnt(0) -- vmcnt retires in order -- and so for every HLL row posted before it).  HLL side: one 16-lane DPP row
+// per destination (lane c = 16-byte chunk c of the 256-byte row); the first kHllInFlight = 12 neighbour chunks per lane are
+// requested up front (ids by one coalesced load per lane group, handed out by DPP row_newbcast), the rest of longer rows after
+// the MinHash walk (hll_row16_finish).  Hub rows are skipped by both sides and
+// served by the two hub kernels afterwards.  P = 64 * PPL, M = 256 (p = 8) only -- the shapes ss_first_hop has a kernel for.
+#include <cstdlib>
+
+#include "ss_walks.hpp"
+
+namespace ss {
+
+constexpr int kFusedRows = 4;
+constexpr int kHllInFlight = 12;
+
+struct HllPosted {  // one lane group's view of its row while the row's first chunks are in flight
+    int64_t i;
+    const int32_t *nb;
+    int deg, total;
+    bool write;
+    u32x4 x[kHllInFlight];
+};
+
+// requests chunk c of the first min(total, kHllInFlight) neighbour rows (the implicit self loop is neighbour `deg`)
+template <int T0>
+__device__ __forceinline__ void hll_post(HllPosted &h, const uint8_t *__restrict__ hll_in, int my_nb, int c)
+{
+    if constexpr (T0 < kHllInFlight) {
+        const int nbt = __builtin_amdgcn_update_dpp(0, my_nb, 0x150 + T0, 0xF, 0xF, false);  // row_newbcast: lane T0 of the 16-lane row
+        const int64_t j = T0 < h.deg ? (int64_t)nbt : h.i;
+        h.x[T0] = u32x4{0u, 0u, 0u, 0u};
+        if (T0 < h.total) h.x[T0] = *reinterpret_cast<const u32x4 *>(hll_in + j * 256 + 16 * c);
+        hll_post<T0 + 1>(h, hll_in, my_nb, c);
+    }
+}
+
+__device__ __forceinline__ u32x4 hll_fold(const HllPosted &h)
+{
+    u32x4 ae = {0u, 0u, 0u, 0u}, ao = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < kHllInFlight; ++k) {
+        ae.x = pk_max_u16(ae.x, h.x[k].x & 0x00FF00FFu); ao.x = pk_max_u16(ao.x, h.x[k].x & 0xFF00FF00u);
+        ae.y = pk_max_u16(ae.y, h.x[k].y & 0x00FF00FFu); ao.y = pk_max_u16(ao.y, h.x[k].y & 0xFF00FF00u);
+        ae.z = pk_max_u16(ae.z, h.x[k].z & 0x00FF00FFu); ao.z = pk_max_u16(ao.z, h.x[k].z & 0xFF00FF00u);
+        ae.w = pk_max_u16(ae.w, h.x[k].w & 0x00FF00FFu); ao.w = pk_max_u16(ao.w, h.x[k].w & 0xFF00FF00u);
+    }
+    return u32x4{ae.x | ao.x, ae.y | ao.y, ae.z | ao.z, ae.w | ao.w};
+}
+
+template <int PPL>
+__global__ __launch_bounds__(256) void first_hop_mh_hll_hop_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
+                                                                   uint32_t *__restrict__ mh_out, int p, const uint8_t *__restrict__ hll_in,
+                                                                   uint8_t *__restrict__ hll_out, float *__restrict__ cards_out,
+                                                                   int64_t cards_stride, ss_hll_params prm, bool skip_hubs)
+{
+    __shared__ EstimatorLds lds;
+    const bool want_cards = cards_out != nullptr;
+    EstimatorTables est = {};
+    if (want_cards) est = stage_tables(lds, prm);  // (barrier inside: before any wavefront leaves)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    MinhashRows<PPL, kFusedRows> m;
+    if (!m.init(g, g.row0 + ((int64_t)blockIdx.x * (blockDim.x / kWave) + wave) * kFusedRows, pa, pb, p, skip_hubs)) return;
+
+    const int grp = m.lane >> 4, c = m.lane & (kRow - 1);
+    // the row of this lane group: bounds from the MinHash side's one rowptr load, first neighbour ids by one 64-byte load
+    HllPosted h;
+    const bool ok = grp < m.rows;
+    const int rel0 = __shfl(m.rel, ok ? grp : 0), rel1 = __shfl(m.rel, ok ? grp + 1 : 0);
+    h.i = m.i0 + (ok ? grp : 0);
+    h.nb = m.nb + rel0;
+    h.deg = ok ? rel1 - rel0 : 0;
+    const bool hub = skip_hubs && h.deg > g.hub_threshold;
+    h.write = ok && !hub;
+    h.total = h.write ? h.deg + (h.i < m.n_self ? 1 : 0) : 0;
+    const int my_nb = (ok && c < h.deg) ? h.nb[c] : 0;
+    hll_post<0>(h, hll_in, my_nb, c);                          // HLL rows of the four destinations: on their way
+#pragma unroll 1
+    for (int r = 0; r < m.rows; ++r) m.row(r, mh_out);          // MinHash first hop of the same rows: VALU work under them
+    const u32x4 acc = hll_fold(h);
+    hll_row16_finish(h.i, h.write, h.nb, h.deg, h.total, acc, kHllInFlight, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c);
+}
+
+// ---- persistent, software-pipelined form -------------------------------------------------------------------------------------
+// At 123 VGPRs only four wavefronts share a SIMD, too few to hide the three dependent round trips at the head of a chunk (row
+// bounds -> neighbour ids -> HLL rows): the one-chunk-per-wavefront kernel above gains 6 % over the two separate launches.  Here a
+// wavefront keeps walking chunks (chunk = kFusedRows rows; chunk q, q + waves, ...) and the loads of the NEXT chunks are posted
+// before the MinHash walk of the current one:
+//     ids(k) arrive  ->  post HLL rows(k)  ->  post ids(k+1) [bounds(k+1) arrived an iteration ago]  ->  post bounds(k+2)
+//     ->  MinHash walk(k)  [VALU; everything above travels]  ->  fold HLL rows(k), finish, store
+// vmcnt retires in order and that is exactly the order of use, so no wait ever covers a younger load.
+// Measured (bench graph): two separate launches 82 + 102 = 184 us; one chunk per wavefront 174 us; this kernel 166-170 us (step
+// 0.494 -> 0.478 ms).  The VALU work alone would be ~120 us: what is left are the loads of rows with more than 12 neighbours, issued
+// and awaited after the walk.  A rolling window (fold four posted chunks after every MinHash row and re-post their registers with the
+// row's next four neighbours) covered 24 neighbours but cost 157-167 VGPRs (three wavefronts per SIMD): 181-196 us.  Not shipped.
+template <int PPL>
+__global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
+                                                                   uint32_t *__restrict__ mh_out, int p, const uint8_t *__restrict__ hll_in,
+                                                                   uint8_t *__restrict__ hll_out, float *__restrict__ cards_out,
+                                                                   int64_t cards_stride, ss_hll_params prm, bool skip_hubs)
+{
+    constexpr int R = kFusedRows, kNb = kWave - R;
+    __shared__ EstimatorLds lds;
+    const bool want_cards = cards_out != nullptr;
+    EstimatorTables est = {};
+    if (want_cards) est = stage_tables(lds, prm);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t n_chunks = (g.rows() + R - 1) / R;
+    const int64_t stride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    int64_t chunk = (int64_t)blockIdx.x * (blockDim.x / kWave) + wave;
+    if (chunk >= n_chunks) return;
+    MinhashRows<PPL, R> m;
+    m.setup(g, pa, pb, p, skip_hubs);
+    const int lane = m.lane, grp = lane >> 4, c = lane & (kRow - 1);
+
+    auto chunk_rows = [&](int64_t q) -> int { return q < n_chunks ? (int)(g.row1 - (g.row0 + q * R) < R ? g.row1 - (g.row0 + q * R) : R) : 0; };
+    auto load_bounds = [&](int64_t q) -> int64_t {  // lane l: rowptr[first row of chunk q + l]
+        const int nr = chunk_rows(q);
+        return (nr > 0 && lane <= nr) ? g.rowptr[g.row0 + q * R + lane] : 0;
+    };
+    // what a lane fetches for a chunk whose bounds have arrived: its batch id (MinHash side) and its lane group's neighbour id (HLL side)
+    struct Ids { int64_t nid; int my_nb; };
+    auto load_ids = [&](int64_t q, int64_t rp) -> Ids {
+        const int nr = chunk_rows(q);
+        if (nr == 0) return Ids{0, 0};
+        const int64_t first = g.row0 + q * R;
+        const int64_t c_lo = ((int64_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)rp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)rp);
+        const int rel = (int)(rp - c_lo);
+        const int c_n = __builtin_amdgcn_readlane(rel, nr);
+        const int32_t *nb = g.col + c_lo;
+        Ids out;
+        out.nid = lane >= kNb ? first + (lane - kNb) : (lane < c_n ? (int64_t)nb[lane] : 0);
+        const bool ok = grp < nr;
+        const int rel0 = __shfl(rel, ok ? grp : 0), rel1 = __shfl(rel, ok ? grp + 1 : 0);
+        out.my_nb = (ok && c < rel1 - rel0) ? nb[rel0 + c] : 0;
+        return out;
+    };
+
+    // prologue: bounds of the first two chunks, ids of the first
+    int64_t rp_cur = load_bounds(chunk);
+    int64_t rp_next = load_bounds(chunk + stride);
+    Ids ids_cur = load_ids(chunk, rp_cur);
+
+    for (; chunk < n_chunks; chunk += stride) {  // wave-uniform
+        const int64_t first = g.row0 + chunk * R;
+        m.begin(g, first, chunk_rows(chunk), rp_cur);
+        m.set_batch(ids_cur.nid);
+        // HLL side of this chunk: the row of this lane group
+        HllPosted h;
+        const bool ok = grp < m.rows;
+        const int rel0 = __shfl(m.rel, ok ? grp : 0), rel1 = __shfl(m.rel, ok ? grp + 1 : 0);
+        h.i = m.i0 + (ok ? grp : 0);
+        h.nb = m.nb + rel0;
+        h.deg = ok ? rel1 - rel0 : 0;
+        const bool hub = skip_hubs && h.deg > g.hub_threshold;
+        h.write = ok && !hub;
+        h.total = h.write ? h.deg + (h.i < m.n_self ? 1 : 0) : 0;
+        hll_post<0>(h, hll_in, ids_cur.my_nb, c);              // HLL rows of chunk k
+        const Ids ids_next = load_ids(chunk + stride, rp_next); // ids of chunk k + 1 (its bounds arrived during the last walk)
+        const int64_t rp_after = load_bounds(chunk + 2 * stride);  // bounds of chunk k + 2
+#pragma unroll 1
+        for (int r = 0; r < m.rows; ++r) m.row(r, mh_out);       // MinHash first hop of chunk k: VALU work under all of the above
+        const u32x4 acc = hll_fold(h);
+        hll_row16_finish(h.i, h.write, h.nb, h.deg, h.total, acc, kHllInFlight, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c);
+        rp_cur = rp_next;
+        rp_next = rp_after;
+        ids_cur = ids_next;
+    }
+}
+
+}  // namespace ss
+
+extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, const uint64_t *b, int32_t P, uint32_t *mh1_out,
+                                  uint32_t *mh2_out, int32_t p, const uint8_t *hll1_in, uint8_t *hll2_out, float *cards2_out,
+                                  int64_t cards_stride, const ss_hll_params *prm, void *stream)
+{
+    using namespace ss;
+    if (!graph || graph->num_nodes < 0 || !graph->rowptr) return SS_ERR_INVALID_ARG;
+    if (p != 8 || P <= 0 || P % kWave || P > 256) return SS_ERR_UNSUPPORTED;  // caller uses ss_first_hop + ss_propagate
+    if (mh2_out && P != 128) return SS_ERR_UNSUPPORTED;                        // the hub pass of the table hop is P = 128 only
+    const int64_t N = graph->num_nodes;
+    if (N == 0) return SS_OK;
+    if (!mh1_out || !a || !b || !hll1_in || !hll2_out || N >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
+    if ((graph->hub_rows == nullptr) != (graph->hub_count == nullptr)) return SS_ERR_INVALID_ARG;
+    ss_hll_params p0 = {};
+    if (cards2_out) {
+        const int rc = check_params(prm);
+        if (rc != SS_OK) return rc;
+        if (prm->p != p) return SS_ERR_INVALID_ARG;
+        p0 = *prm;
+    }
+    if (!row_range_ok(*graph)) return SS_ERR_INVALID_ARG;
+    const GraphArgs g = to_args(*graph);
+    if (g.rows() == 0) return SS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool hubs = g.hub_rows && g.hub_count;
+    constexpr int rows_per_block = 4 * kFusedRows;
+    const unsigned blocks = (unsigned)((g.rows() + rows_per_block - 1) / rows_per_block);
+    static const bool persistent = !(getenv("SS_FUSED_PERSISTENT") && atoi(getenv("SS_FUSED_PERSISTENT")) == 0);
+    static const int wg_per_cu = getenv("SS_FUSED_WG_PER_CU") ? atoi(getenv("SS_FUSED_WG_PER_CU")) : 8;  // 4 resident per CU (128 VGPRs): two rounds balance the tail (165.9 vs 169.9 us)
+    {
+        ProfileSpan span(s, SS_PROF_FUSED);
+        if (persistent) {
+            const unsigned grid = blocks < (unsigned)(256 * wg_per_cu) ? blocks : (unsigned)(256 * wg_per_cu);
+            switch (P / kWave) {
+                case 1: hipLaunchKernelGGL((fused_hop_persistent_kernel<1>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+                case 2: hipLaunchKernelGGL((fused_hop_persistent_kernel<2>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+                case 3: hipLaunchKernelGGL((fused_hop_persistent_kernel<3>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+                default: hipLaunchKernelGGL((fused_hop_persistent_kernel<4>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+            }
+        } else {
+            switch (P / kWave) {
+                case 1: hipLaunchKernelGGL((first_hop_mh_hll_hop_kernel<1>), dim3(blocks), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+                case 2: hipLaunchKernelGGL((first_hop_mh_hll_hop_kernel<2>), dim3(blocks), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+                case 3: hipLaunchKernelGGL((first_hop_mh_hll_hop_kernel<3>), dim3(blocks), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+                default: hipLaunchKernelGGL((first_hop_mh_hll_hop_kernel<4>), dim3(blocks), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+            }
+        }
+    }
+    SS_LAUNCH_CHECK();
+    // hub rows of the hop-1 MinHash table (from node ids): they must be in place before anything reads that table
+    int rc = launch_first_hop_hub_only(g, a, b, P, mh1_out, p, nullptr, nullptr, 0, p0, s);
+    if (rc != SS_OK) return rc;
+    if (!mh2_out)  // hop-2 HLL hub rows alone
+        return launch_propagate_hub_only(g, nullptr, nullptr, hll1_in, hll2_out, cards2_out, cards_stride, p0, s);
+    // MinHash table hop of hop 2, then ONE hub pass for both hop-2 sketches
+    rc = launch_minhash_hop(g, mh1_out, mh2_out, hubs, s);
+    if (rc != SS_OK) return rc;
+    return launch_propagate_hub_only(g, mh1_out, mh2_out, hll1_in, hll2_out, cards2_out, cards_stride, p0, s);
+}

@@ -287,6 +287,16 @@ int launch_propagate(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out
     return SS_OK;
 }
 
+// the MinHash table hop of the regular rows alone (P = 128), for ss_fused_hop_stage
+int launch_minhash_hop(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, bool skip_hubs, hipStream_t stream)
+{
+    ProfileSpan span(stream, SS_PROF_MINHASH_HOP);
+    hipLaunchKernelGGL((propagate_kernel<128, 256>), dim3((unsigned)((g.rows() + 3) / 4)), dim3(256), 0, stream, g, mh_in, mh_out, 128,
+                       (const uint8_t *)nullptr, (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, ss_hll_params{}, skip_hubs);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
 int launch_propagate_hub_only(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, const uint8_t *hll_in, uint8_t *hll_out,
                               float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
 {

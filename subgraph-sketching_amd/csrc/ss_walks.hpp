@@ -279,29 +279,192 @@ __device__ __forceinline__ bool first_hop_minhash_fast(const int32_t *__restrict
     return ambiguous;
 }
 
+// ---- MinHash first hop of R consecutive rows by one wavefront (first_hop_rows_kernel, first_hop_mh_hll_hop_kernel) ------
+// init() reads the bounds of all rows with one load (lane l holds rowptr[first + l] as an offset from the first row's start),
+// the permutation parameters, and the first batch; load_batch() fetches 64 - R consecutive `col` entries of the chunk and
+// hashes them, one per lane -- lanes 64 - R .. 63 always carry the hashes of the rows' OWN ids, so the implicit self loop of
+// row r is slot 64 - R + r of whatever batch is current; row(r) walks row r over its slice of the batch(es) with the
+// two-phase evaluation (first_hop_minhash_fast above), evaluates the winner exactly and stores the row.  Rows flagged
+// ambiguous (and rows that list themselves: duplicates of the implicit self loop) are redone by the exact walk.
+template <int PPL, int R>
+struct MinhashRows {
+    static constexpr int P = PPL * kWave;
+    static constexpr int kNb = kWave - R;  // col entries per batch
+    int lane, rows, rel, c_n, base, p, hub_threshold;
+    bool skip_hubs;
+    int64_t i0, n_self, nid;
+    const int32_t *nb;
+    uint64_t a[PPL], b[PPL];
+    uint32_t a_lo[PPL], b8[PPL], hv_lo, hv_hi;
+
+    __device__ __forceinline__ void load_batch() { set_batch(batch_id()); }
+
+    // once per wavefront: lane constants (permutation parameters, self-loop count, hub rule)
+    __device__ __forceinline__ void setup(const GraphArgs &g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb, int p_, bool skip)
+    {
+        lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            a[q] = pa[lane + kWave * q];
+            b[q] = pb[lane + kWave * q];
+            a_lo[q] = (uint32_t)a[q];
+            b8[q] = (uint32_t)b[q] + 8u;
+        }
+        n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
+        p = p_;
+        skip_hubs = skip;
+        hub_threshold = g.hub_threshold;
+    }
+
+    // rows [first_row, first_row + n_rows) become the current chunk; rp: lane l holds rowptr[first_row + l] (l <= n_rows)
+    __device__ __forceinline__ void begin(const GraphArgs &g, int64_t first_row, int n_rows, int64_t rp)
+    {
+        i0 = first_row;
+        rows = n_rows;
+        const int64_t c_lo = ((int64_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)rp >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)rp);
+        rel = (int)(rp - c_lo);
+        c_n = __builtin_amdgcn_readlane(rel, rows);  // col entries of the whole chunk
+        nb = g.col + c_lo;
+        base = 0;  // chunk-relative position of the current batch's first col entry
+    }
+
+    // the id lane `lane` contributes to the batch at `base`: a col entry, or (lanes kNb..) the id of one of the chunk's own rows
+    __device__ __forceinline__ int64_t batch_id() const
+    {
+        const int t = base + lane;
+        return lane >= kNb ? i0 + (lane - kNb) : (t < c_n ? (int64_t)nb[t] : 0);
+    }
+    __device__ __forceinline__ void set_batch(int64_t id)
+    {
+        nid = id;
+        const uint64_t hv = hash_u64((uint64_t)(nid + 1));
+        hv_lo = (uint32_t)hv;
+        hv_hi = (uint32_t)(hv >> 32);
+    }
+
+    // false: this wavefront owns no row of [g.row0, g.row1)
+    __device__ __forceinline__ bool init(const GraphArgs &g, int64_t first_row, const uint64_t *__restrict__ pa,
+                                         const uint64_t *__restrict__ pb, int p_, bool skip)
+    {
+        if (first_row >= g.row1) return false;
+        const int n_rows = (int)(g.row1 - first_row < R ? g.row1 - first_row : R);
+        const int l = threadIdx.x & (kWave - 1);
+        const int64_t rp = l <= n_rows ? g.rowptr[first_row + l] : 0;
+        setup(g, pa, pb, p_, skip);
+        begin(g, first_row, n_rows, rp);
+        load_batch();
+        return true;
+    }
+
+    __device__ __forceinline__ void row(int r, uint32_t *__restrict__ mh_out)
+    {
+        const int64_t i = i0 + r;
+        const int p0 = __builtin_amdgcn_readlane(rel, r), p1 = __builtin_amdgcn_readlane(rel, r + 1);
+        const int deg = p1 - p0;
+        if (skip_hubs && deg > hub_threshold) return;  // left to first_hop_hub_kernel
+        const bool self = i < n_self;
+        uint32_t acc[PPL];
+        bool redo = false;
+        if (deg + (self ? 1 : 0) == 0) {
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) acc[q] = 0u;  // no in-edge, no self loop: all-zero row (PyG default)
+        } else {
+            uint32_t m1[PPL], m2[PPL], h1_lo[PPL], h1_hi[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                m1[q] = m2[q] = 0xFFFFFFFFu;
+                h1_lo[q] = h1_hi[q] = 0u;
+            }
+            auto update = [&](uint32_t h_lo, uint32_t slot) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+                    const uint32_t x = a_lo[q] * h_lo + b8[q];
+                    uint32_t key;
+                    asm("v_bfi_b32 %0, 63, %1, %2" : "=v"(key) : "s"(slot), "v"(x));  // (x & ~63) | slot, see first_hop_minhash_fast
+                    m2[q] = umed3(m1[q], m2[q], key);
+                    m1[q] = key < m1[q] ? key : m1[q];
+                }
+            };
+            int pos = p0;
+            bool seen_self = false;
+            for (;;) {
+                if (pos < p1 && pos >= base + kNb) {  // the row starts (or continues) beyond the current batch
+                    base += (pos - base) / kNb * kNb;  // (a skipped hub row may lie in between: jump, do not step)
+                    load_batch();
+                }
+                const int s_lo = pos - base;
+                const int s_hi = p1 - base < kNb ? p1 - base : kNb;
+                uint32_t before[PPL];
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) before[q] = m1[q];
+                // a row that lists itself would meet its implicit self loop as a duplicate (ambiguous for every permutation)
+                seen_self |= __any(lane >= s_lo && lane < s_hi && nid == i);
+                int k = s_lo;
+                for (; k + 3 < s_hi; k += 4) {
+                    uint32_t hl[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) hl[u] = (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k + u);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) update(hl[u], (uint32_t)(k + u));
+                }
+                for (; k < s_hi; ++k) update((uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k), (uint32_t)k);
+                pos = base + (s_hi > s_lo ? s_hi : s_lo);
+                const bool last = pos >= p1;
+                if (last && self && !seen_self) update((uint32_t)__builtin_amdgcn_readlane((int)hv_lo, kNb + r), (uint32_t)(kNb + r));
+                // the batch's hashes still sit one per lane: fetch the one whose slot now holds the smallest key
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+                    const int slot = (int)(m1[q] & 63u);
+                    const uint32_t cand_lo = (uint32_t)__shfl((int)hv_lo, slot), cand_hi = (uint32_t)__shfl((int)hv_hi, slot);
+                    const bool changed = m1[q] != before[q];
+                    h1_lo[q] = changed ? cand_lo : h1_lo[q];
+                    h1_hi[q] = changed ? cand_hi : h1_hi[q];
+                }
+                if (last) break;
+            }
+            bool ambiguous = false;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                // x = a * h + b (mod 2^64); the permuted hash is x mod (2^61 - 1) = (x & M) + (x >> 61) [- M], whose low word
+                // is lo32(x) + (x >> 61) unless the sum reaches M -- only possible when bits 32..60 of x are all ones: such
+                // a row (2^-29 per evaluation) is flagged and redone exactly like the key collisions
+                const uint64_t lo = (uint64_t)a_lo[q] * h1_lo[q] + b[q];
+                const uint32_t hi = (uint32_t)(lo >> 32) + a_lo[q] * h1_hi[q] + (uint32_t)(a[q] >> 32) * h1_lo[q];
+                acc[q] = (uint32_t)lo + (hi >> 29);
+                ambiguous |= ((hi & 0x1FFFFFFFu) == 0x1FFFFFFFu) | (m1[q] < 64u) | ((m2[q] >> 6) - (m1[q] >> 6) <= 1u);
+            }
+            redo = __any(ambiguous);
+        }
+        if (redo) {
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
+            first_hop_walk<PPL, true, false>(nb + p0, deg, deg + (self ? 1 : 0), i, 0, 1, p, a, b, acc, nullptr, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = acc[q];
+    }
+};
+
 // HLL table hop for FOUR destination rows per wavefront: one 16-lane DPP row per destination, lane c owns the 16-byte
 // chunk c of the 256-byte HLL row.  Compared with one destination per wave (hll_walk + two cross-group shuffles +
 // an epilogue that uses 16 of 64 lanes) this keeps 4x the loads in flight per wave and runs the cardinality
 // epilogue for 4 rows at once.  `row` < 0 marks an inactive group.  M = 256 only.
-__device__ __forceinline__ void hll_hop_row16(const GraphArgs &g, int64_t row, bool skip_hubs, const uint8_t *__restrict__ hll_in,
-                                              uint8_t *__restrict__ hll_out, float *__restrict__ cards_out, int64_t cards_stride,
-                                              const EstimatorTables &est, bool want_cards, int c /* lane & 15 */)
+// everything after the first `walked` neighbours of the four rows of a wavefront have been folded into `acc` (one 16-lane
+// group per row, lane c = chunk c): the rest of rows up to kSolo neighbours by their own group, what is left of longer rows
+// by all four groups together, then the row's statistics, its store and its cardinality.  `total` = 0 marks a group without
+// a row to write (past the end, or a hub row left to the hub pass).
+__device__ __forceinline__ void hll_row16_finish(int64_t i, bool write, const int32_t *__restrict__ nb, int deg, int total, u32x4 acc,
+                                                 int walked, const uint8_t *__restrict__ hll_in, uint8_t *__restrict__ hll_out,
+                                                 float *__restrict__ cards_out, int64_t cards_stride, const EstimatorTables &est,
+                                                 bool want_cards, int c /* lane & 15 */)
 {
     constexpr int M = 256;
-    const bool ok = row >= 0;
-    const int64_t i = ok ? row : 0;
-    const int64_t rb = g.rowptr[i];
-    const int deg = (int)(g.rowptr[i + 1] - rb);
-    const bool hub = skip_hubs && deg > g.hub_threshold;
-    const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
-    const int total = (!ok || hub) ? 0 : deg + (i < n_self ? 1 : 0);
     // every lane group walks the first kSolo neighbours of its own row; what is left of longer rows is walked by the whole
     // wavefront, one row at a time (group g takes every 4th neighbour), so a wavefront lasts about sum(excess)/4 instead
     // of max(degree) iterations -- skewed graphs put rows of 10 and of 500 neighbours into the same wavefront
     constexpr int kSolo = 32;
-    const int32_t *nb = g.col + rb;
-    u32x4 acc = hll_walk_first16(hll_in, nb, deg, total, i, c);
-    if (__any(total > 16)) acc = bytemax16(acc, hll_walk(hll_in, nb, deg, total < kSolo ? total : kSolo, i, 16, 1, M, c));
+    if (__any(total > walked)) acc = bytemax16(acc, hll_walk(hll_in, nb, deg, total < kSolo ? total : kSolo, i, walked, 1, M, c));
     const unsigned long long long_rows = __ballot(total > kSolo);
     if (long_rows) {
         const int grp = (threadIdx.x & (kWave - 1)) / kRow;
@@ -330,10 +493,26 @@ __device__ __forceinline__ void hll_hop_row16(const GraphArgs &g, int64_t row, b
         nonzero = row16_sum_i(nonzero);
         hsum = row16_sum_f(hsum);
     }
-    if (ok && !hub) {
+    if (write) {
         *reinterpret_cast<u32x4 *>(hll_out + i * M + 16 * c) = acc;
         if (want_cards && c == 0) cards_out[i * cards_stride] = hll_estimate(est, M - nonzero, hsum);
     }
+}
+
+__device__ __forceinline__ void hll_hop_row16(const GraphArgs &g, int64_t row, bool skip_hubs, const uint8_t *__restrict__ hll_in,
+                                              uint8_t *__restrict__ hll_out, float *__restrict__ cards_out, int64_t cards_stride,
+                                              const EstimatorTables &est, bool want_cards, int c /* lane & 15 */)
+{
+    const bool ok = row >= 0;
+    const int64_t i = ok ? row : 0;
+    const int64_t rb = g.rowptr[i];
+    const int deg = (int)(g.rowptr[i + 1] - rb);
+    const bool hub = skip_hubs && deg > g.hub_threshold;
+    const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
+    const int total = (!ok || hub) ? 0 : deg + (i < n_self ? 1 : 0);
+    const int32_t *nb = g.col + rb;
+    const u32x4 acc = hll_walk_first16(hll_in, nb, deg, total, i, c);
+    hll_row16_finish(i, ok && !hub, nb, deg, total, acc, 16, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c);
 }
 
 // hub-row-only launches (defined in ss_first_hop.hip / ss_propagate.hip) for kernels that skip hub rows themselves
@@ -341,5 +520,6 @@ int launch_first_hop_hub_only(const GraphArgs &g, const uint64_t *a, const uint6
                               float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream);
 int launch_propagate_hub_only(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, const uint8_t *hll_in, uint8_t *hll_out,
                               float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream);
+int launch_minhash_hop(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, bool skip_hubs, hipStream_t stream);
 
 }  // namespace ss

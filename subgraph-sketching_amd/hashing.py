@@ -612,6 +612,7 @@ class HllPropagation(object):
 # ------------------------------------------------------------------------------------------------
 class ElphHashes(object):
     """class to store hashes and retrieve subgraph features (mirror of reference hashing.py:48-323)"""
+    FUSED_STAGE_MAX_TABLE_BYTES = 256 << 20  # ss_fused_hop_stage is used while the hop-1 HLL table fits the Infinity Cache
 
     def __init__(self, args):
         assert args.max_hash_hops in {1, 2, 3}, f'hashing is not implemented for {args.max_hash_hops} hops'
@@ -643,6 +644,8 @@ class ElphHashes(object):
         self._dev_params = {}
         self._dev_perms = {}
         self.fuse_first_hop = True  # compute hop 1 straight from node ids when the fused kernel supports (num_perm, p)
+        # hop-1 MinHash + hop-2 HLL in one launch (ss_fused_hop_stage; num_perm == 128, hll_p == 8, max_hops >= 2, unsharded build)
+        self.fuse_hop_stage = os.environ.get('SS_FUSED_STAGE', '1') != '0'
         self.strict_bounds = True  # raise IndexError for out-of-range node ids (costs one 4-byte D2H per call)
 
     # no device handles in pickled state (SURVEY.md section 8(b) threading row)
@@ -783,7 +786,24 @@ class ElphHashes(object):
             mh_prev = self._init_minhash_u32(num_nodes, device)  # hop 0 is replicated: a pure function of the node id
             hll_prev = self._init_hll_u8(num_nodes, device)
             table[0] = HopSketch(mh_prev, hll_prev, home)
-        if shard is None:
+        # (only while the hop-1 HLL table the stage gathers from fits the 256 MiB Infinity Cache: collab-like -2 %, ppa-like -3 % per
+        # step; citation2-like, 750 MB of HBM-resident random gathers at the stage's 4 wavefronts per SIMD, +1.5 %)
+        if (shard is None and fused and h >= 2 and self.num_perm == 128 and self.fuse_hop_stage
+                and num_nodes * self.m <= self.FUSED_STAGE_MAX_TABLE_BYTES):
+            # hop-1 HLL first (hop-2 HLL rows need that table complete), then ONE stage for hop-1 MinHash + hop-2 HLL (the
+            # VALU-bound first hop and the memory-bound table hop interleaved inside every wavefront, csrc/ss_fused_hop.hip)
+            # + hop-2 MinHash; further hops unfused
+            self._first_hop(csr, device, None, hll[0], cards, params)
+            ab = self._perms(device)
+            graph = csr.struct()
+            with _Span('fused_hop_stage', device):
+                _native.check(_native.lib().ss_fused_hop_stage(byref(graph), _ptr(ab[0]), _ptr(ab[1]), self.num_perm, _ptr(mh[0]), _ptr(mh[1]),
+                                                               self.p, _ptr(hll[0]), _ptr(hll[1]), _ptr(cards[:, 1]), h, byref(params.struct),
+                                                               _stream(device)), 'ss_fused_hop_stage')
+            for k in range(3, h + 1):
+                _propagate(csr, mh[k - 2], hll[k - 2], device, cards_out=cards[:, k - 1], cards_stride=h, params=params,
+                           mh_out=mh[k - 1], hll_out=hll[k - 1])
+        elif shard is None:
             # (inside the library each of these calls is one launch per sketch + one hub pass: measured faster than
             # two-sketch kernels -- first hop 37 + 134 us vs 184, table hop 111 + 192 us vs 326 on the bench graph)
             for k in range(1, h + 1):

@@ -37,6 +37,8 @@ def kernel_bytes(N, E, P=128, p=8, h=2, B=65536):
         'hll_hop': (Ep + N) * M + graph_read_bytes(N, E) + 4 * N,           # + cards[:, k-1]
         'minhash_hop': (Ep + N) * 4 * P + graph_read_bytes(N, E),
         'pair_features': B * pair_bytes(P, p, h),
+        # ss_fused_hop_stage's kernel: MinHash first hop + HLL table hop of hop 2 in one launch (the CSR is read once)
+        'fused_first_hop_hll_hop': graph_read_bytes(N, E) + N * 4 * P + (Ep + N) * M + 4 * N,
     }
 
 
