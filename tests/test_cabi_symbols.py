@@ -68,6 +68,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ss_minhash_init(None, 0, 0, None, None, 128, None) == 0        # empty is fine
     assert lib.ss_hll_init(None, 0, 10, 3, None) == -1                        # p < 4
     assert lib.ss_pack_minhash(None, None, -1, None) == -1
+    assert lib.ss_fused_hop_stage(None, None, None, 128, None, None, 8, None, None, None, 0, None, None) == -1   # no graph
     assert lib.ss_pair_features(None, 0, 0, 4, None, 128, None, None, 0, None, 0, None, None, None, None, None, None) == -4  # h = 4
 
 
