@@ -27,7 +27,7 @@ extern "C" {
 #define SS_PROF_PAIRS 4           /* ss::pair_features_kernel                                                            */
 #define SS_PROF_CSR 5             /* all launches of one ss_csr_build                                                    */
 #define SS_PROF_HUB 6             /* hub / mega-row passes (propagate_hub_kernel, first_hop_hub_kernel)                  */
-#define SS_PROF_FUSED 7           /* ss::first_hop_mh_hll_hop_kernel (MinHash first hop + HLL table hop in one launch)     */
+#define SS_PROF_FUSED 7           /* ss::fused_hop_persistent_kernel (MinHash first hop + HLL table hop in one launch)     */
 #define SS_PROF_TAGS 8
 int ss_profile_enable(uint32_t tag_mask);   /* bit t enables family t; 0 disables everything */
 int ss_profile_read(int32_t tag, float *mean_ms_out, int32_t *launches_out);

@@ -65,43 +65,10 @@ __device__ __forceinline__ u32x4 hll_fold(const HllPosted &h)
     return u32x4{ae.x | ao.x, ae.y | ao.y, ae.z | ao.z, ae.w | ao.w};
 }
 
-template <int PPL>
-__global__ __launch_bounds__(256) void first_hop_mh_hll_hop_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
-                                                                   uint32_t *__restrict__ mh_out, int p, const uint8_t *__restrict__ hll_in,
-                                                                   uint8_t *__restrict__ hll_out, float *__restrict__ cards_out,
-                                                                   int64_t cards_stride, ss_hll_params prm, bool skip_hubs)
-{
-    __shared__ EstimatorLds lds;
-    const bool want_cards = cards_out != nullptr;
-    EstimatorTables est = {};
-    if (want_cards) est = stage_tables(lds, prm);  // (barrier inside: before any wavefront leaves)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    MinhashRows<PPL, kFusedRows> m;
-    if (!m.init(g, g.row0 + ((int64_t)blockIdx.x * (blockDim.x / kWave) + wave) * kFusedRows, pa, pb, p, skip_hubs)) return;
-
-    const int grp = m.lane >> 4, c = m.lane & (kRow - 1);
-    // the row of this lane group: bounds from the MinHash side's one rowptr load, first neighbour ids by one 64-byte load
-    HllPosted h;
-    const bool ok = grp < m.rows;
-    const int rel0 = __shfl(m.rel, ok ? grp : 0), rel1 = __shfl(m.rel, ok ? grp + 1 : 0);
-    h.i = m.i0 + (ok ? grp : 0);
-    h.nb = m.nb + rel0;
-    h.deg = ok ? rel1 - rel0 : 0;
-    const bool hub = skip_hubs && h.deg > g.hub_threshold;
-    h.write = ok && !hub;
-    h.total = h.write ? h.deg + (h.i < m.n_self ? 1 : 0) : 0;
-    const int my_nb = (ok && c < h.deg) ? h.nb[c] : 0;
-    hll_post<0>(h, hll_in, my_nb, c);                          // HLL rows of the four destinations: on their way
-#pragma unroll 1
-    for (int r = 0; r < m.rows; ++r) m.row(r, mh_out);          // MinHash first hop of the same rows: VALU work under them
-    const u32x4 acc = hll_fold(h);
-    hll_row16_finish(h.i, h.write, h.nb, h.deg, h.total, acc, kHllInFlight, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c);
-}
-
-// ---- persistent, software-pipelined form -------------------------------------------------------------------------------------
-// At 123 VGPRs only four wavefronts share a SIMD, too few to hide the three dependent round trips at the head of a chunk (row
-// bounds -> neighbour ids -> HLL rows): the one-chunk-per-wavefront kernel above gains 6 % over the two separate launches.  Here a
-// wavefront keeps walking chunks (chunk = kFusedRows rows; chunk q, q + waves, ...) and the loads of the NEXT chunks are posted
+// ---- the kernel: persistent, software-pipelined -------------------------------------------------------------------------------
+// At ~125 VGPRs only four wavefronts share a SIMD, too few to hide the three dependent round trips at the head of a chunk (row
+// bounds -> neighbour ids -> HLL rows): a one-chunk-per-wavefront form of this kernel gained 6 % over the two separate launches
+// (174 us against 184).  Here a wavefront keeps walking chunks (chunk = kFusedRows rows; chunk q, q + waves, ...) and the loads of the NEXT chunks are posted
 // before the MinHash walk of the current one:
 //     ids(k) arrive  ->  post HLL rows(k)  ->  post ids(k+1) [bounds(k+1) arrived an iteration ago]  ->  post bounds(k+2)
 //     ->  MinHash walk(k)  [VALU; everything above travels]  ->  fold HLL rows(k), finish, store
@@ -213,25 +180,16 @@ extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, 
     const bool hubs = g.hub_rows && g.hub_count;
     constexpr int rows_per_block = 4 * kFusedRows;
     const unsigned blocks = (unsigned)((g.rows() + rows_per_block - 1) / rows_per_block);
-    static const bool persistent = !(getenv("SS_FUSED_PERSISTENT") && atoi(getenv("SS_FUSED_PERSISTENT")) == 0);
-    static const int wg_per_cu = getenv("SS_FUSED_WG_PER_CU") ? atoi(getenv("SS_FUSED_WG_PER_CU")) : 8;  // 4 resident per CU (128 VGPRs): two rounds balance the tail (165.9 vs 169.9 us)
+    // 4 workgroups are resident per CU (128 VGPRs); twice that many balance the tail (165.9 against 169.9 us on the bench graph)
+    static const int wg_per_cu = getenv("SS_FUSED_WG_PER_CU") ? atoi(getenv("SS_FUSED_WG_PER_CU")) : 8;
+    const unsigned grid = blocks < (unsigned)(256 * wg_per_cu) ? blocks : (unsigned)(256 * wg_per_cu);
     {
         ProfileSpan span(s, SS_PROF_FUSED);
-        if (persistent) {
-            const unsigned grid = blocks < (unsigned)(256 * wg_per_cu) ? blocks : (unsigned)(256 * wg_per_cu);
-            switch (P / kWave) {
-                case 1: hipLaunchKernelGGL((fused_hop_persistent_kernel<1>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-                case 2: hipLaunchKernelGGL((fused_hop_persistent_kernel<2>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-                case 3: hipLaunchKernelGGL((fused_hop_persistent_kernel<3>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-                default: hipLaunchKernelGGL((fused_hop_persistent_kernel<4>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-            }
-        } else {
-            switch (P / kWave) {
-                case 1: hipLaunchKernelGGL((first_hop_mh_hll_hop_kernel<1>), dim3(blocks), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-                case 2: hipLaunchKernelGGL((first_hop_mh_hll_hop_kernel<2>), dim3(blocks), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-                case 3: hipLaunchKernelGGL((first_hop_mh_hll_hop_kernel<3>), dim3(blocks), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-                default: hipLaunchKernelGGL((first_hop_mh_hll_hop_kernel<4>), dim3(blocks), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-            }
+        switch (P / kWave) {
+            case 1: hipLaunchKernelGGL((fused_hop_persistent_kernel<1>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+            case 2: hipLaunchKernelGGL((fused_hop_persistent_kernel<2>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+            case 3: hipLaunchKernelGGL((fused_hop_persistent_kernel<3>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+            default: hipLaunchKernelGGL((fused_hop_persistent_kernel<4>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
         }
     }
     SS_LAUNCH_CHECK();

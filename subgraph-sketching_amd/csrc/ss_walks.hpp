@@ -279,7 +279,7 @@ __device__ __forceinline__ bool first_hop_minhash_fast(const int32_t *__restrict
     return ambiguous;
 }
 
-// ---- MinHash first hop of R consecutive rows by one wavefront (first_hop_rows_kernel, first_hop_mh_hll_hop_kernel) ------
+// ---- MinHash first hop of R consecutive rows by one wavefront (first_hop_rows_kernel, fused_hop_persistent_kernel) ------
 // init() reads the bounds of all rows with one load (lane l holds rowptr[first + l] as an offset from the first row's start),
 // the permutation parameters, and the first batch; load_batch() fetches 64 - R consecutive `col` entries of the chunk and
 // hashes them, one per lane -- lanes 64 - R .. 63 always carry the hashes of the rows' OWN ids, so the implicit self loop of
@@ -446,10 +446,6 @@ struct MinhashRows {
     }
 };
 
-// HLL table hop for FOUR destination rows per wavefront: one 16-lane DPP row per destination, lane c owns the 16-byte
-// chunk c of the 256-byte HLL row.  Compared with one destination per wave (hll_walk + two cross-group shuffles +
-// an epilogue that uses 16 of 64 lanes) this keeps 4x the loads in flight per wave and runs the cardinality
-// epilogue for 4 rows at once.  `row` < 0 marks an inactive group.  M = 256 only.
 // everything after the first `walked` neighbours of the four rows of a wavefront have been folded into `acc` (one 16-lane
 // group per row, lane c = chunk c): the rest of rows up to kSolo neighbours by their own group, what is left of longer rows
 // by all four groups together, then the row's statistics, its store and its cardinality.  `total` = 0 marks a group without
@@ -499,6 +495,10 @@ __device__ __forceinline__ void hll_row16_finish(int64_t i, bool write, const in
     }
 }
 
+// HLL table hop for FOUR destination rows per wavefront: one 16-lane DPP row per destination, lane c owns the 16-byte
+// chunk c of the 256-byte HLL row.  Compared with one destination per wave (hll_walk + two cross-group shuffles +
+// an epilogue that uses 16 of 64 lanes) this keeps 4x the loads in flight per wave and runs the cardinality
+// epilogue for 4 rows at once.  `row` < 0 marks an inactive group.  M = 256 only.
 __device__ __forceinline__ void hll_hop_row16(const GraphArgs &g, int64_t row, bool skip_hubs, const uint8_t *__restrict__ hll_in,
                                               uint8_t *__restrict__ hll_out, float *__restrict__ cards_out, int64_t cards_stride,
                                               const EstimatorTables &est, bool want_cards, int c /* lane & 15 */)
