@@ -19,7 +19,7 @@ import subgraph_sketching_amd as ssa  # noqa: E402
 
 FAMILIES = [('propagate_kernel<128, 256>', 'minhash_hop'), ('hll_propagate_row16_kernel', 'hll_hop'),
             ('first_hop_kernel<2, true, false>', 'first_hop_minhash'), ('first_hop_rows_kernel<2', 'first_hop_minhash'),
-            ('hll_first_hop_kernel', 'first_hop_hll'),
+            ('hll_first_hop_kernel', 'first_hop_hll'), ('fused_hop_persistent_kernel', 'fused_first_hop_hll_hop'),
             ('pair_features_kernel', 'pair_features')]
 
 
