@@ -76,7 +76,8 @@ __device__ __forceinline__ u32x4 hll_fold(const HllPosted &h)
 // Measured (bench graph): two separate launches 82 + 102 = 184 us; one chunk per wavefront 174 us; this kernel 166-170 us (step
 // 0.494 -> 0.478 ms).  The VALU work alone would be ~120 us: what is left are the loads of rows with more than 12 neighbours, issued
 // and awaited after the walk.  A rolling window (fold four posted chunks after every MinHash row and re-post their registers with the
-// row's next four neighbours) covered 24 neighbours but cost 157-167 VGPRs (three wavefronts per SIMD): 181-196 us.  Not shipped.
+// row's next four neighbours) covered 24 neighbours but cost 157-167 VGPRs (three wavefronts per SIMD): 181-196 us; a single re-post of
+// 8 chunks before the last MinHash row (coverage 16, 134 VGPRs): 184 us.  Not shipped: the kernel lives on its fourth wavefront.
 template <int PPL>
 __global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
                                                                    uint32_t *__restrict__ mh_out, int p, const uint8_t *__restrict__ hll_in,
