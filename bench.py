@@ -179,9 +179,14 @@ def main():
     eh.strict_bounds = False  # no host sync inside a step
     nf = h * (h + 2)
 
-    plan = ssa.dist.BatchPlan(a.scaling, world, rank, batch)
+    # BUDDY: the link set is a multiple of the batch; ONE plan / one gather covers all of it (a gather per batch would cost ~30 us
+    # each, several times a rank's share of a batch at 8 GPUs); strong scaling cuts the link set into contiguous slices
+    buddy_links = a.buddy_links or min(cfg['buddy_links'], 64 * batch)
+    buddy_batches = max(1, math.ceil(buddy_links / batch))
+    pairs_planned = batch * buddy_batches if a.api == 'buddy' else batch
+    plan = ssa.dist.BatchPlan(a.scaling, world, rank, pairs_planned)
     ei_np = synthetic_graph(n, e_und, a.graph, a.alpha)
-    links_np = synthetic_links(n, batch, plan.links_seed)
+    links_np = synthetic_links(n, pairs_planned, plan.links_seed)
     ei = torch.from_numpy(ei_np).to(dev)
     links = plan.local(torch.from_numpy(links_np).to(dev)).contiguous()
     gather = ssa.dist.AsyncFeatureGather(plan, nf, dev) if launched else (lambda f: f)
@@ -227,21 +232,16 @@ def main():
         gather(f)
         return f
 
-    # BUDDY: the link set is a multiple of the batch; strong scaling shards every batch (the same slice of fresh pairs)
-    buddy_links = a.buddy_links or min(cfg['buddy_links'], 64 * batch)
-    buddy_batches = max(1, math.ceil(buddy_links / batch))
-
     def step_buddy(mark=False):
-        """one build, then the whole link set in batches of B pairs (datasets/elph.py:200-208)"""
+        """one build, then this rank's share of the whole link set in chunks of B pairs (datasets/elph.py:200-208:
+        get_subgraph_features(links, hashes, cards, subgraph_feature_batch_size)), one gather of all feature rows"""
         table, cards = build_tables()
-        for _ in range(buddy_batches):
-            f = eh.get_subgraph_features(links, table, cards)
-            gather(f)
+        f = eh.get_subgraph_features(links, table, cards, batch_size=batch)
+        gather(f)
         return f
 
     step = {'build_query': step_build_query, 'elph': step_elph, 'buddy': step_buddy}[a.api]
-    batches_per_step = buddy_batches if a.api == 'buddy' else 1
-    pairs_per_step = plan.pairs_per_step * batches_per_step  # whole job, all ranks
+    pairs_per_step = plan.pairs_per_step  # whole job, all ranks (BUDDY: the whole link set)
 
     def fence():
         if launched:
@@ -294,7 +294,7 @@ def main():
             step()
         fence()
         lib.ss_profile_enable(0)
-        model = rf.kernel_bytes(n, e_dir, P, HLL_P, h, links.size(0))
+        model = rf.kernel_bytes(n, e_dir, P, HLL_P, h, min(links.size(0), batch))
         kernel_table = {}
         for name, tag in tags.items():
             ms, cnt = c_float(), c_int32()
@@ -335,9 +335,9 @@ def main():
         'vs_baseline': None, 'dtype': 'u32/u8 sketches, f32 estimator', 'data': 'synthetic',
         'config': {'workload': f'ogbl-{a.config}-like synthetic {a.graph} graph' + (' (BASELINE configs[1])' if a.config == 'collab' else '') +
                                ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps' +
-                               ('' if a.api == 'build_query' else f' [api mode: {a.api}' + (f', {buddy_batches} batches per build' if a.api == 'buddy' else '') + ']'),
+                               ('' if a.api == 'build_query' else f' [api mode: {a.api}' + (f', {buddy_batches} batches of {batch} pairs per build' if a.api == 'buddy' else '') + ']'),
                    'num_nodes': n, 'directed_edges': e_dir, 'max_hash_hops': h, 'minhash_num_perm': P, 'hll_p': HLL_P,
-                   'pairs_per_step_per_gpu': links.size(0) * batches_per_step, 'global_pairs_per_step': pairs_per_step,
+                   'pairs_per_step_per_gpu': links.size(0), 'global_pairs_per_step': pairs_per_step,
                    'parallelism': (f'edge batches sharded x{world} ({a.scaling} scaling), all_gather of features; sketch table ' +
                                    (f'built row-sharded x{world} with an in-place all_gather per hop and sketch' if sharded_build
                                     else 'replicated (every rank builds it)')),

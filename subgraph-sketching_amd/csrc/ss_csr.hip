@@ -518,6 +518,8 @@ __device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds
             excl[b0 + k] = ex;
             if (node0 + b0 + k < N) {
                 rowptr[node0 + b0 + k] = (int64_t)(seg_lo + ex);
+                // (cross-workgroup appends: agent-scope atomics on the counters, plain stores into the claimed slots; nothing in
+                // THIS launch reads the lists -- the propagation launches do, and a kernel boundary orders them behind these stores)
                 if (hub_rows && c > (uint32_t)hub_threshold) {
                     if (mega_rows && c > (uint32_t)SS_MEGA_SLICE) {  // walked slice by slice by all hub workgroups
                         const int slices = (int)((c + 1 + SS_MEGA_SLICE - 1) / SS_MEGA_SLICE);  // + 1: the implicit self loop
