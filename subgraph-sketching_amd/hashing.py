@@ -282,6 +282,12 @@ def unpack_minhash(x_u32):
 
 
 LAZY_MINHASH = True  # minhash_prop returns its int64 result as a LazyMinhash (materialised on first outside use)
+# ELPH.forward (reference models/elph.py:209-212) calls hll_prop then minhash_prop per hop.  With this on, the hop-1 minhash_prop
+# (input: an unmodified hop-0 tensor) only RECORDS its work; the hop-2 hll_prop that follows on the same edge_index computes the
+# hop-1 MinHash rows together with its own HLL rows in one launch (ss_fused_hop_stage: the VALU-bound first hop under the
+# memory-bound table hop).  Anything else that needs the table first (the next minhash_prop, get_subgraph_features, any torch
+# operator on the tensor) triggers the ordinary first-hop launch.  Same results either way.
+DEFER_FIRST_HOP = os.environ.get('SS_FUSED_STAGE', '1') != '0'
 
 
 class LazyMinhash(torch.Tensor):
@@ -297,21 +303,33 @@ class LazyMinhash(torch.Tensor):
     __torch_function__ = torch._C._disabled_torch_function_impl
 
     @staticmethod
-    def __new__(cls, packed):
+    def __new__(cls, packed, pending=None):
         return torch.Tensor._make_wrapper_subclass(cls, packed.shape, dtype=torch.int64, device=packed.device, requires_grad=False)
 
-    def __init__(self, packed):
-        self._packed, self._real = packed, None
+    def __init__(self, packed, pending=None):
+        """pending: a zero-argument callable that FILLS `packed` (deferred first hop, see MinhashPropagation.forward); it is
+        run the first time the table is needed -- or never, when HllPropagation computes the table on the way (fused stage)"""
+        self._packed, self._real, self._pending = packed, None, pending
+
+    def resolve(self):
+        """run the deferred computation of the packed table, if there is one"""
+        if self._pending is not None:
+            fill, self._pending = self._pending, None
+            fill()
 
     def materialise(self):
         if self._real is None:
+            self.resolve()
             self._real = unpack_minhash(self._packed)
             self._packed = None
         return self._real
 
     def packed_if_valid(self):
         """the packed table while nothing outside the engine has seen (and possibly edited) the int64 form"""
-        return self._packed if self._real is None else None
+        if self._real is not None:
+            return None
+        self.resolve()
+        return self._packed
 
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
@@ -406,6 +424,7 @@ class CsrGraph(object):
         self.hub_rows, self.hub_count, self.hub_threshold = hub_rows, hub_count, hub_threshold
         self.mega_rows, self.mega_count, self.mega_scratch = mega if mega is not None else (None, None, None)
         self.has_hub_rows = True  # unknown (no host read of the device counters): keep the hub passes
+        self.pending_minhash = None  # (weakref to a LazyMinhash, perms, P, p): a deferred hop-1 MinHash table on this graph
         self.use_inferred_self_loops = False
 
     def struct(self, rows=None):
@@ -556,6 +575,18 @@ class MinhashPropagation(object):
         out_u32 = None
         if hop0 is not None and hop0[0] is not None:
             out_u32 = torch.empty((x.size(0), x.size(1)), dtype=torch.int32, device=device)
+            P, p = x.size(1), hop0[1]
+            if (DEFER_FIRST_HOP and LAZY_MINHASH and x.device == device and p == 8 and P % 64 == 0 and P <= 256
+                    and x.size(0) * 256 <= ElphHashes.FUSED_STAGE_MAX_TABLE_BYTES):
+                perms = hop0[0]
+
+                def fill(csr=csr, perms=perms, P=P, p=p, out=out_u32, device=device):
+                    csr.pending_minhash = None
+                    if not _first_hop_from_ids(csr, device, perms, P, p, out, None):  # pragma: no cover (shapes checked above)
+                        raise RuntimeError('deferred MinHash first hop has no kernel for this shape')
+                lazy = LazyMinhash(out_u32, pending=fill)
+                csr.pending_minhash = (weakref.ref(lazy), perms, P, p)  # the hop-2 hll_prop on this CSR may take it over
+                return lazy
             if not _first_hop_from_ids(csr, device, hop0[0], x.size(1), hop0[1], out_u32, None):
                 out_u32 = None
         if out_u32 is None:
@@ -593,6 +624,22 @@ class HllPropagation(object):
         if hop0 is not None and hop0[0] is None and M == 256:
             out_u8 = torch.empty((x.size(0), M), dtype=torch.uint8, device=device)
             if not _first_hop_from_ids(csr, device, None, 128, hop0[1], None, out_u8, counts, params):
+                out_u8 = None
+        pend = getattr(csr, 'pending_minhash', None)
+        lazy = pend[0]() if pend is not None else None
+        if out_u8 is None and lazy is not None and lazy._pending is not None and M == 256 and params is not None:
+            # a hop-1 MinHash table is still owed on this CSR (deferred by minhash_prop): compute it together with these HLL rows
+            _, perms, P, p = pend
+            out_u8 = torch.empty((x.size(0), M), dtype=torch.uint8, device=device)
+            graph = csr.struct()
+            with _Span('fused_hop_stage', device):
+                rc = _native.lib().ss_fused_hop_stage(byref(graph), _ptr(perms[0]), _ptr(perms[1]), P, _ptr(lazy._packed), None, p,
+                                                      _ptr(_packed_hll_of(x, device)), _ptr(out_u8), _ptr(counts), 1, byref(params.struct),
+                                                      _stream(device))
+            if rc == 0:
+                lazy._pending = None
+                csr.pending_minhash = None
+            else:  # pragma: no cover (shapes were checked when the work was deferred)
                 out_u8 = None
         if out_u8 is None:
             _, out_u8 = _propagate(csr, None, _packed_hll_of(x, device), device, cards_out=counts, cards_stride=1, params=params)
