@@ -135,14 +135,15 @@ int ss_first_hop(const ss_csr_graph *graph, const uint64_t *a, const uint64_t *b
                  uint32_t *mh_out, int32_t p, uint8_t *hll_out, float *cards_out, int64_t cards_stride,
                  const ss_hll_params *prm, void *stream);
 
-/* Hops 1 and 2 of a build after the hop-1 HLL table is complete (ss_first_hop with mh_out == NULL): writes the hop-1 MinHash
- * rows (from node ids), the hop-2 HLL rows + their cardinalities (cards2_out[i * cards_stride], nullable) and -- when mh2_out is
- * given (P == 128) -- the hop-2 MinHash rows.  Same results as ss_first_hop(MinHash) + ss_propagate(both sketches)
- * (hashing.py:118-124, 28-45 at k = 1, 2, 163), but the VALU-bound MinHash first hop and the memory-bound HLL table hop run
- * interleaved inside one launch (csrc/ss_fused_hop.hip).  hll1_in: the COMPLETE hop-1 HLL table.  Returns SS_ERR_UNSUPPORTED
- * outside p == 8, P % 64 == 0, P <= 256: the caller then uses the unfused calls. */
+/* Hops 1 and 2 of a build in one call: the hop-1 MinHash rows (from node ids), the hop-2 HLL rows + their cardinalities and --
+ * when mh2_out is given (P == 128) -- the hop-2 MinHash rows; with cards1_out != NULL also the hop-1 HLL rows (`hll1` is then an
+ * OUTPUT, cards1_out[i * cards_stride] their cardinalities), with cards1_out == NULL `hll1` is the COMPLETE hop-1 HLL table as
+ * input.  Same results as ss_first_hop + ss_propagate (hashing.py:118-137, 28-45 at k = 1, 2, 163), but the VALU-bound MinHash first
+ * hop and the memory-bound HLL table hop of hop 2 run interleaved inside one launch (csrc/ss_fused_hop.hip).  cards2_out:
+ * nullable unless cards1_out is given.  Returns SS_ERR_UNSUPPORTED outside p == 8, P % 64 == 0, P <= 256: the caller then uses the
+ * unfused calls. */
 int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, const uint64_t *b, int32_t P, uint32_t *mh1_out,
-                       uint32_t *mh2_out, int32_t p, const uint8_t *hll1_in, uint8_t *hll2_out, float *cards2_out,
+                       uint32_t *mh2_out, int32_t p, uint8_t *hll1, float *cards1_out, uint8_t *hll2_out, float *cards2_out,
                        int64_t cards_stride, const ss_hll_params *prm, void *stream);
 
 /* HLL++ cardinality of n register rows.  Replaces ElphHashes.hll_count (+ _linearcounting,

@@ -396,6 +396,17 @@ void launch_minhash_rows(const GraphArgs &g, const uint64_t *a, const uint64_t *
     else go(std::integral_constant<int, kRowsPerWave>{});
 }
 
+// HLL first hop of the regular rows alone (ss_fused_hop_stage owns the hub pass that follows)
+int launch_hll_first_hop_rows(const GraphArgs &g, int p, uint8_t *hll_out, float *cards_out, int64_t cards_stride, const ss_hll_params &prm,
+                              bool skip_hubs, hipStream_t s)
+{
+    ProfileSpan span(s, SS_PROF_FIRST_HOP_HLL);
+    hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows))), dim3(256), 0, s, g, p, hll_out,
+                       cards_out, cards_stride, prm, skip_hubs);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
 template <int PPL>
 int launch_first_hop(const GraphArgs &g, const uint64_t *a, const uint64_t *b, uint32_t *mh_out, int p, uint8_t *hll_out,
                      float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t s)

@@ -9,9 +9,11 @@
 //
 // Data dependencies make this the only such pair of a build: hop-2 HLL rows need the COMPLETE hop-1 HLL table (so the HLL first
 // hop and its hub pass run before this launch); hop-1 MinHash rows need nothing but the graph.  A build of h >= 2 hops is
-//     ss_first_hop (HLL only: hop-1 HLL + cards)  ->  ss_fused_hop_stage [this file]  ->  ss_propagate for hops 3..h
-// where ss_fused_hop_stage = this kernel, the hub pass of the hop-1 MinHash rows, the MinHash table hop of hop 2
-// (propagate_kernel<128,256>) and ONE hub pass for both hop-2 sketches: one hub launch more than the unfused schedule.
+//     ss_fused_hop_stage [this file]  ->  ss_propagate for hops 3..h
+// where ss_fused_hop_stage = HLL first hop of the regular rows, ONE hub pass for both hop-1 sketches, this kernel, the MinHash
+// table hop of hop 2 (propagate_kernel<128,256>) and ONE hub pass for both hop-2 sketches -- as many hub launches as the unfused
+// schedule.  (With cards1_out == NULL the hop-1 HLL table is an input -- the deferred first hop of the ELPH call sequence, hashing.py
+// DEFER_FIRST_HOP -- and the hop-1 MinHash hub rows get a pass of their own after the kernel.)
 // Results are bit-identical to the unfused sequence: the MinHash side is MinhashRows (ss_walks.hpp, shared with
 // first_hop_rows_kernel), the HLL side folds the same rows with the same byte-wise max and runs the same cardinality epilogue.
 //
@@ -156,9 +158,10 @@ __global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, 
 }  // namespace ss
 
 extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, const uint64_t *b, int32_t P, uint32_t *mh1_out,
-                                  uint32_t *mh2_out, int32_t p, const uint8_t *hll1_in, uint8_t *hll2_out, float *cards2_out,
+                                  uint32_t *mh2_out, int32_t p, uint8_t *hll1, float *cards1_out, uint8_t *hll2_out, float *cards2_out,
                                   int64_t cards_stride, const ss_hll_params *prm, void *stream)
 {
+    const uint8_t *hll1_in = hll1;
     using namespace ss;
     if (!graph || graph->num_nodes < 0 || !graph->rowptr) return SS_ERR_INVALID_ARG;
     if (p != 8 || P <= 0 || P % kWave || P > 256) return SS_ERR_UNSUPPORTED;  // caller uses ss_first_hop + ss_propagate
@@ -179,6 +182,16 @@ extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, 
     if (g.rows() == 0) return SS_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool hubs = g.hub_rows && g.hub_count;
+    const bool own_hop1 = cards1_out != nullptr;  // the hop-1 HLL table is computed here as well (build_hash_tables)
+    if (own_hop1) {
+        if (!cards2_out) return SS_ERR_INVALID_ARG;
+        int rc1 = launch_hll_first_hop_rows(g, p, hll1, cards1_out, cards_stride, p0, hubs, s);
+        if (rc1 != SS_OK) return rc1;
+        // ONE hub pass from node ids for both hop-1 sketches: the MinHash hub rows are not needed before the table hop below,
+        // but computing them here saves the hub launch after the fused kernel
+        rc1 = launch_first_hop_hub_only(g, a, b, P, mh1_out, p, hll1, cards1_out, cards_stride, p0, s);
+        if (rc1 != SS_OK) return rc1;
+    }
     constexpr int rows_per_block = 4 * kFusedRows;
     const unsigned blocks = (unsigned)((g.rows() + rows_per_block - 1) / rows_per_block);
     // 4 workgroups are resident per CU (128 VGPRs); twice that many balance the tail (165.9 against 169.9 us on the bench graph)
@@ -195,7 +208,7 @@ extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, 
     }
     SS_LAUNCH_CHECK();
     // hub rows of the hop-1 MinHash table (from node ids): they must be in place before anything reads that table
-    int rc = launch_first_hop_hub_only(g, a, b, P, mh1_out, p, nullptr, nullptr, 0, p0, s);
+    int rc = own_hop1 ? SS_OK : launch_first_hop_hub_only(g, a, b, P, mh1_out, p, nullptr, nullptr, 0, p0, s);
     if (rc != SS_OK) return rc;
     if (!mh2_out)  // hop-2 HLL hub rows alone
         return launch_propagate_hub_only(g, nullptr, nullptr, hll1_in, hll2_out, cards2_out, cards_stride, p0, s);

@@ -521,5 +521,7 @@ int launch_first_hop_hub_only(const GraphArgs &g, const uint64_t *a, const uint6
 int launch_propagate_hub_only(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, const uint8_t *hll_in, uint8_t *hll_out,
                               float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream);
 int launch_minhash_hop(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, bool skip_hubs, hipStream_t stream);
+int launch_hll_first_hop_rows(const GraphArgs &g, int p, uint8_t *hll_out, float *cards_out, int64_t cards_stride, const ss_hll_params &prm,
+                              bool skip_hubs, hipStream_t stream);
 
 }  // namespace ss

@@ -634,8 +634,8 @@ class HllPropagation(object):
             graph = csr.struct()
             with _Span('fused_hop_stage', device):
                 rc = _native.lib().ss_fused_hop_stage(byref(graph), _ptr(perms[0]), _ptr(perms[1]), P, _ptr(lazy._packed), None, p,
-                                                      _ptr(_packed_hll_of(x, device)), _ptr(out_u8), _ptr(counts), 1, byref(params.struct),
-                                                      _stream(device))
+                                                      _ptr(_packed_hll_of(x, device)), None, _ptr(out_u8), _ptr(counts), 1,
+                                                      byref(params.struct), _stream(device))
             if rc == 0:
                 lazy._pending = None
                 csr.pending_minhash = None
@@ -837,16 +837,15 @@ class ElphHashes(object):
         # step; citation2-like, 750 MB of HBM-resident random gathers at the stage's 4 wavefronts per SIMD, +1.5 %)
         if (shard is None and fused and h >= 2 and self.num_perm == 128 and self.fuse_hop_stage
                 and num_nodes * self.m <= self.FUSED_STAGE_MAX_TABLE_BYTES):
-            # hop-1 HLL first (hop-2 HLL rows need that table complete), then ONE stage for hop-1 MinHash + hop-2 HLL (the
-            # VALU-bound first hop and the memory-bound table hop interleaved inside every wavefront, csrc/ss_fused_hop.hip)
-            # + hop-2 MinHash; further hops unfused
-            self._first_hop(csr, device, None, hll[0], cards, params)
+            # ONE call for hops 1 and 2: hop-1 HLL first (hop-2 HLL rows need that table complete), then hop-1 MinHash + hop-2 HLL
+            # in one launch (the VALU-bound first hop and the memory-bound table hop interleaved inside every wavefront,
+            # csrc/ss_fused_hop.hip), then hop-2 MinHash; further hops unfused
             ab = self._perms(device)
             graph = csr.struct()
             with _Span('fused_hop_stage', device):
                 _native.check(_native.lib().ss_fused_hop_stage(byref(graph), _ptr(ab[0]), _ptr(ab[1]), self.num_perm, _ptr(mh[0]), _ptr(mh[1]),
-                                                               self.p, _ptr(hll[0]), _ptr(hll[1]), _ptr(cards[:, 1]), h, byref(params.struct),
-                                                               _stream(device)), 'ss_fused_hop_stage')
+                                                               self.p, _ptr(hll[0]), _ptr(cards), _ptr(hll[1]), _ptr(cards[:, 1]), h,
+                                                               byref(params.struct), _stream(device)), 'ss_fused_hop_stage')
             for k in range(3, h + 1):
                 _propagate(csr, mh[k - 2], hll[k - 2], device, cards_out=cards[:, k - 1], cards_stride=h, params=params,
                            mh_out=mh[k - 1], hll_out=hll[k - 1])

@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_strings():
     import subgraph_sketching_amd as ssa
     lib = ssa._native.lib()
-    assert lib.ss_version() == 121 == ssa._native.ABI_VERSION
+    assert lib.ss_version() == 122 == ssa._native.ABI_VERSION
     assert lib.ss_error_string(0) == b'ok'
     assert b'invalid' in lib.ss_error_string(-1)
     assert lib.ss_csr_workspace_bytes(1000, 5000) >= 8 * 1001
@@ -68,7 +68,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ss_minhash_init(None, 0, 0, None, None, 128, None) == 0        # empty is fine
     assert lib.ss_hll_init(None, 0, 10, 3, None) == -1                        # p < 4
     assert lib.ss_pack_minhash(None, None, -1, None) == -1
-    assert lib.ss_fused_hop_stage(None, None, None, 128, None, None, 8, None, None, None, 0, None, None) == -1   # no graph
+    assert lib.ss_fused_hop_stage(None, None, None, 128, None, None, 8, None, None, None, None, 0, None, None) == -1   # no graph
     assert lib.ss_pair_features(None, 0, 0, 4, None, 128, None, None, 0, None, 0, None, None, None, None, None, None) == -4  # h = 4
 
 
