@@ -31,7 +31,7 @@ constexpr int kThreads = 256;
 constexpr int kTile = 4096;            // edges sorted in LDS at a time by the scatter step
 constexpr int kMaxKeys = 256;          // partition fan-out per pass
 constexpr int kMaxBlocks1 = 2048;      // pass-1 slices
-constexpr int kFinishThreads = 512;
+constexpr int kFinishThreads = 1024;      // (512: bench graph 46-48 us, rank^-0.5 133-137, rank^-0.9 640; 1024: 45, 121, 567)
 constexpr int kFinishCap = 16384;      // edges staged in LDS by the finish step (64 KiB)
 constexpr int kMaxTiles = 1536;        // single-pass plan: tiles whose run descriptors fit the finish step's LDS beside the image (2 workgroups per CU)
 
