@@ -594,23 +594,25 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__re
 // and then finishes the bucket like finish_kernel.  Replaces count_keys + scan_block_counts + scan_bases + scatter_tiles +
 // finish (61 us on the bench graph, three of the five launches latency-bound small grids).
 
-__global__ __launch_bounds__(kThreads) void tile_sort_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t E,
-                                                             int64_t N, int shift, int keys, int tiles, int2 *__restrict__ staged,
-                                                             uint32_t *__restrict__ tile_off, unsigned long long *__restrict__ tile_max,
-                                                             int32_t *__restrict__ err, int32_t *__restrict__ hub_count,
-                                                             int32_t *__restrict__ mega_count)
+constexpr int kSortThreads = 512;  // 8 edges per thread (256 threads x 16 edges: 19.3 us on the collab-like graph, 512 x 8: 16.1 us)
+
+__global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t E,
+                                                                 int64_t N, int shift, int keys, int tiles, int2 *__restrict__ staged,
+                                                                 uint32_t *__restrict__ tile_off, unsigned long long *__restrict__ tile_max,
+                                                                 int32_t *__restrict__ err, int32_t *__restrict__ hub_count,
+                                                                 int32_t *__restrict__ mega_count)
 {
     __shared__ int2 sorted[kTile];
-    __shared__ uint32_t tile_hist[kMaxKeys], tile_offs[kMaxKeys], wave_tot[kThreads / kWave];
+    __shared__ uint32_t tile_hist[kMaxKeys], tile_offs[kMaxKeys], wave_tot[kSortThreads / kWave];
     __shared__ unsigned long long block_max;
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // outputs of the finish launch of this build are cleared here
         if (hub_count) *hub_count = 0;
         if (mega_count) mega_count[0] = mega_count[1] = 0;
     }
-    tile_hist[threadIdx.x] = 0;
+    if (threadIdx.x < kMaxKeys) tile_hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) block_max = 0;
     __syncthreads();
-    constexpr int PER = kTile / kThreads;  // 16 edges per thread
+    constexpr int PER = kTile / kSortThreads;  // 8 edges per thread
     const int64_t t0 = (int64_t)blockIdx.x * kTile;
     const int64_t hi = t0 + kTile < E ? t0 + kTile : E;
     int64_t my_max = -1;
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(kThreads) void tile_sort_kernel(const int64_t *__re
     uint32_t rank[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int64_t e = t0 + threadIdx.x + (int64_t)k * kThreads;
+        const int64_t e = t0 + threadIdx.x + (int64_t)k * kSortThreads;
         key[k] = -1;
         ed[k] = make_int2(0, 0);
         if (e < hi) {
@@ -637,9 +639,24 @@ __global__ __launch_bounds__(kThreads) void tile_sort_kernel(const int64_t *__re
 #pragma unroll
     for (int k = 0; k < PER; ++k) rank[k] = key[k] >= 0 ? atomicAdd(&tile_hist[key[k]], 1u) : 0u;
     __syncthreads();
-    uint32_t tile_n = 0;
-    const uint32_t ex = block_exclusive_scan_256(tile_hist[threadIdx.x], wave_tot, &tile_n);
-    tile_offs[threadIdx.x] = ex;
+    // exclusive scan of the <= 256 key counts: thread k < 256 owns key k, the other wavefronts contribute zeros
+    const uint32_t mine = threadIdx.x < kMaxKeys ? tile_hist[threadIdx.x] : 0u;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == kWave - 1) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0, tile_n = 0;
+    for (int w = 0; w < kMaxKeys / kWave; ++w) {
+        if (w < wv) pre += wave_tot[w];
+        tile_n += wave_tot[w];
+    }
+    const uint32_t ex = pre + inc - mine;
+    if (threadIdx.x < kMaxKeys) tile_offs[threadIdx.x] = ex;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; ++k)
@@ -647,13 +664,13 @@ __global__ __launch_bounds__(kThreads) void tile_sort_kernel(const int64_t *__re
     if ((int)threadIdx.x < keys) tile_off[(int64_t)threadIdx.x * tiles + blockIdx.x] = ex;
     if (threadIdx.x == 0) tile_off[(int64_t)keys * tiles + blockIdx.x] = tile_n;
     __syncthreads();
-    for (uint32_t q = threadIdx.x; q < tile_n; q += kThreads) staged[t0 + q] = sorted[q];
+    for (uint32_t q = threadIdx.x; q < tile_n; q += kSortThreads) staged[t0 + q] = sorted[q];
     unsigned long long m = my_max < 0 ? 0ULL : (unsigned long long)my_max + 1ULL;
     for (int off = kWave / 2; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_xor(m, off);
         m = o > m ? o : m;
     }
-    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(&block_max, m);
+    if (lane == 0 && m) atomicMax(&block_max, m);
     if (bad && err) *err = 1;
     __syncthreads();
     if (threadIdx.x == 0) tile_max[blockIdx.x] = block_max;
@@ -762,7 +779,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
 
     if (p.gather) {  // <= 256 fine buckets and <= kMaxTiles tiles: two launches, no counting pass, no scan kernels
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(p.tiles), dim3(kThreads), 0, stream, src, dst, E, N, p.shift1, p.keys1, p.tiles, w.staged_a,
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(p.tiles), dim3(kSortThreads), 0, stream, src, dst, E, N, p.shift1, p.keys1, p.tiles, w.staged_a,
                            w.tile_off, w.tile_max, err_flag, hub_count, mega_count);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(finish_gather_kernel, dim3((unsigned)p.fine_buckets), dim3(kFinishThreads), 0, stream, w.staged_a, w.tile_off,
