@@ -176,7 +176,7 @@ def main():
     nat = ssa._native
     lib = nat.lib()  # fails loudly if the HIP engine is missing
     eh = ssa.ElphHashes(Namespace(max_hash_hops=h, hll_p=HLL_P, minhash_num_perm=P, floor_sf=False, use_zero_one=True))
-    eh.strict_bounds = False  # no host sync inside a step
+    assert eh.strict_bounds == 'deferred'  # the class default: bounds errors are reported late, no host sync inside a step
     nf = h * (h + 2)
 
     # BUDDY: the link set is a multiple of the batch; ONE plan / one gather covers all of it (a gather per batch would cost ~30 us
@@ -268,6 +268,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = 1e3 * elapsed / a.steps
+    eh.check_errors()  # the deferred bounds report of every launch so far (none expected on the synthetic workload)
 
     # ---- everything below runs AFTER the timed region ----------------------------------------------------------------
     sustained = None

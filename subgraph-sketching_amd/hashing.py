@@ -97,6 +97,38 @@ def _take_error(device):
     return bad
 
 
+class _DeferredErrors(object):
+    """strict_bounds = 'deferred': kernels report out-of-range node ids into a PINNED HOST int32 (hipHostMalloc memory is
+    mapped into the device's address space at the same address; the store only happens on an error), which the host reads
+    without synchronising: at the next call into the engine, or in ElphHashes.check_errors().  The error therefore
+    surfaces late -- like the device-side assert the reference's torch indexing triggers for CUDA tensors -- but a
+    build + query step stays free of host round trips."""
+
+    def __init__(self):
+        self._flags, self._calls = {}, []
+
+    def flag(self, device, what):
+        key = str(device)
+        if key not in self._flags:
+            self._flags[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._calls.append(what)
+        del self._calls[:-8]
+        return self._flags[key]
+
+    def raise_if_set(self, synchronize=False):
+        for key, flag in self._flags.items():
+            if synchronize:
+                torch.cuda.synchronize(torch.device(key))
+            if int(flag[0]):
+                flag.zero_()
+                calls, self._calls = ', '.join(self._calls), []
+                raise IndexError(f'an earlier call on this engine was given node ids outside its num_nodes (reported late: '
+                                 f'strict_bounds="deferred"); calls since the last clean check: {calls}. Out-of-range edges '
+                                 f'were dropped and out-of-range pairs returned NaN rows')
+        if synchronize:
+            self._calls = []
+
+
 def _check_sizes(num_perm, p):
     if num_perm <= 0 or num_perm % 4 or num_perm > 2048:
         raise NotImplementedError(f'minhash_num_perm must be a multiple of 4 in [4, 2048], got {num_perm}')
@@ -446,9 +478,10 @@ class CsrGraph(object):
                                       row_begin=begin, row_end=end)
 
 
-def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
+def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None, err_flag=None):
     """CSR-by-destination of edge_index [2, E] (flow source -> target, reference hashing.py:34,44).
-    check=True synchronises once to raise IndexError for endpoints outside [0, num_nodes)."""
+    check=True synchronises once to raise IndexError for endpoints outside [0, num_nodes); err_flag (a device-visible
+    int32 tensor, see _DeferredErrors) takes the report instead and nothing synchronises."""
     lib = _native.lib()
     ei = edge_index.to(device=device, dtype=torch.int64)
     if ei.dim() != 2 or ei.size(0) != 2:
@@ -467,7 +500,10 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None):
     mega_count = flags32[4:6]
     # strict mode reads its own flag together with the counters below; a non-strict build passes NO flag (a shared one
     # would stay set and make the next strict call raise for valid inputs)
-    err = flags32[3:4] if check else None
+    if err_flag is not None:
+        check, err = False, err_flag
+    else:
+        err = flags32[3:4] if check else None
     if check:
         err.zero_()
     hub_rows = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=device)
@@ -503,15 +539,18 @@ class _CsrCache(object):
     self-looped edge_index object; this builds its CSR once per forward.  A dead weak reference or a
     bumped `_version` (in-place edit) invalidates the entry, so recycled allocations are never trusted."""
 
-    def __init__(self, check=lambda: True):
+    def __init__(self, check=lambda device, what: (True, None)):
         self._ref, self._version, self._key, self._csr = None, None, None, None
-        self._check = check  # whether a build may synchronise to raise IndexError (ElphHashes.strict_bounds of the owner)
+        # (device, what) -> (check, err_flag) of build_csr: whether a build may synchronise to raise IndexError, or where it
+        # reports instead (ElphHashes._bounds of the owner)
+        self._check = check
 
     def get(self, edge_index, num_nodes, device):
         key = (num_nodes, tuple(edge_index.shape), str(device))
         if self._ref is not None and self._ref() is edge_index and self._version == edge_index._version and self._key == key:
             return self._csr
-        csr = build_csr(edge_index, num_nodes, device, check=bool(self._check()))
+        check, err_flag = self._check(device, 'sketch propagation (edge_index)')
+        csr = build_csr(edge_index, num_nodes, device, check=check, err_flag=err_flag)
         self._ref, self._version, self._key, self._csr = weakref.ref(edge_index), edge_index._version, key, csr
         return csr
 
@@ -671,7 +710,7 @@ class ElphHashes(object):
         self._minhash_range = (1 << 32)
         self.minhash_seed = 1
         self.num_perm = args.minhash_num_perm
-        self._csr_cache = _CsrCache(lambda: self.strict_bounds)
+        self._csr_cache = _CsrCache(self._bounds)
         self.minhash_prop = MinhashPropagation(self._csr_cache)
         # hll params (reference hashing.py:65-81)
         self.p = args.hll_p
@@ -693,20 +732,25 @@ class ElphHashes(object):
         self.fuse_first_hop = True  # compute hop 1 straight from node ids when the fused kernel supports (num_perm, p)
         # hop-1 MinHash + hop-2 HLL in one launch (ss_fused_hop_stage; num_perm == 128, hll_p == 8, max_hops >= 2, unsharded build)
         self.fuse_hop_stage = os.environ.get('SS_FUSED_STAGE', '1') != '0'
-        self.strict_bounds = True  # raise IndexError for out-of-range node ids (costs one 4-byte D2H per call)
+        # node ids outside [0, num_nodes): 'deferred' (default) = IndexError at the NEXT call into this engine or at
+        # check_errors(), no host synchronisation inside a step; True = IndexError from the offending call itself (one
+        # synchronising 4-byte read per CSR build / query call); False = never reported (edges dropped, NaN feature rows)
+        self.strict_bounds = 'deferred'
+        self._deferred = _DeferredErrors()
 
     # no device handles in pickled state (SURVEY.md section 8(b) threading row)
     def __getstate__(self):
         state = dict(self.__dict__)
         state['_dev_params'], state['_dev_perms'] = {}, {}
-        state['_csr_cache'] = None
+        state['_csr_cache'], state['_deferred'] = None, None
         state.pop('_tables_id', None)
         state['minhash_prop'], state['hll_prop'] = None, None
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        self._csr_cache = _CsrCache(lambda: self.strict_bounds)
+        self._deferred = _DeferredErrors()
+        self._csr_cache = _CsrCache(self._bounds)
         self.minhash_prop = MinhashPropagation(self._csr_cache)
         self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m)
 
@@ -798,6 +842,19 @@ class ElphHashes(object):
         return out
 
     # ---- build ---------------------------------------------------------------------------------------
+    def _bounds(self, device, what):
+        """-> (check, err_flag) for a launch that validates node ids, after raising what an earlier deferred launch reported"""
+        if self.strict_bounds == 'deferred':
+            self._deferred.raise_if_set()
+            return False, self._deferred.flag(device, what)
+        return bool(self.strict_bounds), None
+
+    def check_errors(self):
+        """strict_bounds = 'deferred': wait for the launches issued so far and raise IndexError if any of them met a node id
+        outside its num_nodes (call once after preprocessing / at the end of an epoch; every call into the engine also
+        performs the non-waiting form of this check)"""
+        self._deferred.raise_if_set(synchronize=True)
+
     def build_hash_tables(self, num_nodes, edge_index):
         """k-hop sketches of every node, k = 0..max_hops, and their HLL cardinalities (reference :139-165).
         @return: (SketchTable {k: {'hll','minhash'}}, cards float32 [num_nodes, max_hops])"""
@@ -813,7 +870,8 @@ class ElphHashes(object):
         params = self._params(device)
         # add_self_loops without num_nodes (reference :148): loops for i < max(edge_index) + 1 only; the count is
         # produced on the device by ss_csr_build and read by the propagation kernel -- no host round trip
-        csr = build_csr(edge_index, num_nodes, device, check=self.strict_bounds)
+        check, err_flag = self._bounds(device, f'build_hash_tables(num_nodes={num_nodes})')
+        csr = build_csr(edge_index, num_nodes, device, check=check, err_flag=err_flag)
         csr.use_inferred_self_loops = True
         rows = None if shard is None else shard.rows
         n_alloc = num_nodes if shard is None else shard.padded_rows
@@ -948,7 +1006,9 @@ class ElphHashes(object):
         hll_ptrs = (c_void_p * h)(*[t.data_ptr() for t in hll])
         floor = self.floor_sf if floor_sf is None else floor_sf  # DeviceFeatureStore records HashDataset's post-hoc floor
         flags = (_native.SS_FLAG_USE_ZERO_ONE if self.use_zero_one else 0) | (_native.SS_FLAG_FLOOR_SF if floor else 0)
-        err = _error_flag(device) if self.strict_bounds else None  # non-strict launches never touch the shared flag
+        strict, err = self._bounds(device, f'get_subgraph_features({B} links, num_nodes={N})')
+        if strict:
+            err = _error_flag(device)  # (non-strict launches never touch the shared flag)
         if degrees is not None:
             dg = degrees.to(device=device, dtype=torch.float32).contiguous()
             if dg.dim() != 1 or dg.numel() != N:
@@ -958,7 +1018,7 @@ class ElphHashes(object):
                 _native.check(_native.lib().ss_pair_features_normalised(
                     _ptr(lk), B, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0), byref(params.struct), flags, _ptr(dg),
                     _ptr(out), _ptr(err), _stream(device)), 'ss_pair_features_normalised')
-            if self.strict_bounds and B > 0 and _take_error(device):
+            if strict and B > 0 and _take_error(device):
                 raise IndexError(f'links refer to nodes outside [-{N}, {N})')
             return out, None
         out = torch.empty((B, nf), dtype=torch.float32, device=device)
@@ -972,7 +1032,7 @@ class ElphHashes(object):
                 _ptr(lk), B, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0), byref(params.struct), flags, _ptr(out),
                 _ptr(dbg['match']) if dbg else None, _ptr(dbg['zeros']) if dbg else None,
                 _ptr(dbg['inter']) if dbg else None, _ptr(err), _stream(device)), 'ss_pair_features')
-        if self.strict_bounds and B > 0 and _take_error(device):
+        if strict and B > 0 and _take_error(device):
             raise IndexError(f'links refer to nodes outside [-{N}, {N})')
         return out, dbg
 
