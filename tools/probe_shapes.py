@@ -19,6 +19,7 @@ import subgraph_sketching_amd as ssa
 ap = argparse.ArgumentParser()
 ap.add_argument('--json', default=None)
 ap.add_argument('--steps', type=int, default=10)
+ap.add_argument('--only', default=None, help='P,p,h of a single shape (for a rocprofv3 --kernel-trace run)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 n, e_und, B = bench.N_NODES, bench.E_UND, bench.BATCH
@@ -26,8 +27,9 @@ ei = torch.from_numpy(bench.synthetic_graph(n, e_und)).to(dev)
 links = torch.from_numpy(bench.synthetic_links(n, B, 2)).to(dev)
 E = ei.size(1)
 rows = []
-for P, p, h in [(128, 8, 2), (128, 8, 1), (128, 8, 3), (64, 8, 2), (192, 8, 2), (256, 8, 2), (128, 6, 2), (128, 10, 2), (128, 12, 2),
-                (64, 6, 2), (256, 10, 3)]:
+SHAPES = [(128, 8, 2), (128, 8, 1), (128, 8, 3), (64, 8, 2), (192, 8, 2), (256, 8, 2), (128, 6, 2), (128, 10, 2), (128, 12, 2),
+          (64, 6, 2), (256, 10, 3)]
+for P, p, h in ([tuple(int(x) for x in a.only.split(','))] if a.only else SHAPES):
     eh = ssa.ElphHashes(Namespace(max_hash_hops=h, hll_p=p, minhash_num_perm=P, floor_sf=False, use_zero_one=True))
 
     def step():
