@@ -344,9 +344,15 @@ int dispatch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables 
                    int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *dbg_match,
                    int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream)
 {
-    if (P == 128 && M == 256)
-        return launch_pairs<H, 128, 256>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero,
-                                         dbg_inter, err, degrees, stream);
+#define SS_PAIRS_FAST(TP)                                                                                                      \
+    if (P == TP && M == 256)                                                                                                    \
+        return launch_pairs<H, TP, 256>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero,     \
+                                        dbg_inter, err, degrees, stream);
+    SS_PAIRS_FAST(128)  // the reference's default shape
+    SS_PAIRS_FAST(64)   // the other permutation counts the first hop is specialised for (ss_first_hop: P / 64 = 1 .. 4)
+    SS_PAIRS_FAST(192)
+    SS_PAIRS_FAST(256)
+#undef SS_PAIRS_FAST
     return launch_pairs<H, 0, 0>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter,
                                  err, degrees, stream);
 }
