@@ -483,7 +483,8 @@ extern "C" int ss_first_hop(const ss_csr_graph *graph, const uint64_t *a, const 
 {
     using namespace ss;
     if (!graph || graph->num_nodes < 0 || !graph->rowptr) return SS_ERR_INVALID_ARG;
-    if (p != 8 || P <= 0 || P % kWave || P > 256) return SS_ERR_UNSUPPORTED;  // caller falls back to init + propagate
+    // (the MinHash rows do not depend on p: a MinHash-only call is served for every hll_p; the HLL row image is 256 registers)
+    if ((hll_out && p != 8) || P <= 0 || P % kWave || P > 256) return SS_ERR_UNSUPPORTED;  // caller falls back to init + propagate
     const int64_t N = graph->num_nodes;
     if (N == 0) return SS_OK;
     if ((!mh_out && !hll_out) || (mh_out && (!a || !b)) || N >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;  // either sketch may be NULL; a / b only feed MinHash

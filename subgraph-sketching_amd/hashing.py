@@ -878,7 +878,9 @@ class ElphHashes(object):
         cards = torch.empty((n_alloc, self.max_hops), dtype=torch.float32, device=device)
         table = SketchTable()
         h = self.max_hops
-        fused = self.fuse_first_hop and self.p == 8 and self.num_perm % 64 == 0 and self.num_perm <= 256
+        # hop 1 from node ids: MinHash for 64 / 128 / 192 / 256 permutations at any hll_p, HLL at hll_p == 8
+        fused_mh = self.fuse_first_hop and self.num_perm % 64 == 0 and self.num_perm <= 256
+        fused = fused_mh and self.p == 8
         mh = [torch.empty((n_alloc, self.num_perm), dtype=torch.int32, device=device) for _ in range(h)]
         hll = [torch.empty((n_alloc, self.m), dtype=torch.uint8, device=device) for _ in range(h)]
         if fused:
@@ -887,6 +889,10 @@ class ElphHashes(object):
             table[0] = HopSketch(None, None, home, make_packed=lambda n=num_nodes, d=device: (self._init_minhash_u32(n, d),
                                                                                             self._init_hll_u8(n, d)))
             mh_prev = hll_prev = None
+        elif fused_mh:
+            hll_prev = self._init_hll_u8(num_nodes, device)
+            table[0] = HopSketch(None, None, home, make_packed=lambda n=num_nodes, d=device, l=hll_prev: (self._init_minhash_u32(n, d), l))
+            mh_prev = None
         else:
             mh_prev = self._init_minhash_u32(num_nodes, device)  # hop 0 is replicated: a pure function of the node id
             hll_prev = self._init_hll_u8(num_nodes, device)
@@ -913,6 +919,9 @@ class ElphHashes(object):
             for k in range(1, h + 1):
                 if k == 1 and fused:
                     self._first_hop(csr, device, mh[0], hll[0], cards, params)
+                elif k == 1 and fused_mh:
+                    self._first_hop(csr, device, mh[0], None, None, params)
+                    _propagate(csr, None, hll_prev, device, cards_out=cards[:, 0], cards_stride=h, params=params, hll_out=hll[0])
                 else:
                     logger.info(f"Calculating hop {k} hashes")
                     _propagate(csr, mh_prev, hll_prev, device, cards_out=cards[:, k - 1], cards_stride=h, params=params,
@@ -922,7 +931,7 @@ class ElphHashes(object):
             pending_mh = pending_hll = None
             for k in range(1, h + 1):
                 shard.wait(pending_mh)  # hop k-1 MinHash rows of every rank have arrived
-                if k == 1 and fused:
+                if k == 1 and fused_mh:
                     self._first_hop(csr, device, mh[0], None, None, params, rows=rows)
                 else:
                     _propagate(csr, mh_prev, None, device, mh_out=mh[k - 1], rows=rows)
