@@ -53,6 +53,20 @@ __device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
     const uint32_t o = pk_max_u16(a & 0xFF00FF00u, b & 0xFF00FF00u);
     return e | o;
 }
+// running byte-wise max of many 16-byte chunks as packed u16: `ae` holds the even bytes (masked in), `ao` the odd ones -- for those
+// the chunk goes in UNMASKED: a u16 max is decided by its high byte, so the high byte of every half of `ao` is the max of the odd
+// bytes seen, whatever its low byte has become (12 instead of 16 instructions per chunk; hll_acc_result masks once at the end)
+__device__ __forceinline__ void hll_acc(u32x4 &ae, u32x4 &ao, const u32x4 &x)
+{
+    ae.x = pk_max_u16(ae.x, x.x & 0x00FF00FFu); ao.x = pk_max_u16(ao.x, x.x);
+    ae.y = pk_max_u16(ae.y, x.y & 0x00FF00FFu); ao.y = pk_max_u16(ao.y, x.y);
+    ae.z = pk_max_u16(ae.z, x.z & 0x00FF00FFu); ao.z = pk_max_u16(ao.z, x.z);
+    ae.w = pk_max_u16(ae.w, x.w & 0x00FF00FFu); ao.w = pk_max_u16(ao.w, x.w);
+}
+__device__ __forceinline__ u32x4 hll_acc_result(const u32x4 &ae, const u32x4 &ao)
+{
+    return u32x4{ae.x | (ao.x & 0xFF00FF00u), ae.y | (ao.y & 0xFF00FF00u), ae.z | (ao.z & 0xFF00FF00u), ae.w | (ao.w & 0xFF00FF00u)};
+}
 __device__ __forceinline__ u32x4 bytemax16(u32x4 a, u32x4 b)
 {
     u32x4 r;

@@ -31,7 +31,11 @@
 namespace ss {
 
 constexpr int kFusedRows = 4;
-constexpr int kHllInFlight = 12;
+#ifndef SS_HLL_INFLIGHT
+#define SS_HLL_INFLIGHT 11
+#define SS_HLL_LDS 5
+#endif
+constexpr int kHllInFlight = SS_HLL_INFLIGHT;
 
 struct HllPosted {  // one lane group's view of its row while the row's first chunks are in flight
     int64_t i;
@@ -54,17 +58,30 @@ __device__ __forceinline__ void hll_post(HllPosted &h, const uint8_t *__restrict
     }
 }
 
-__device__ __forceinline__ u32x4 hll_fold(const HllPosted &h)
+// neighbour rows kHllInFlight .. kHllInFlight + kHllLds - 1 of every lane group travel into LDS instead of registers
+// (global_load_lds_dwordx4: no VGPR destination; one instruction = one neighbour of each of the wavefront's four rows, landing as
+// 64 lanes x 16 B = 1 KiB at the wave-uniform LDS address): rows of up to 16 neighbours need no load after the MinHash walk
+constexpr int kHllLds = SS_HLL_LDS;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(1))) const uint32_t global_u32;
+
+template <int T>
+__device__ __forceinline__ void hll_post_lds(const HllPosted &h, const uint8_t *__restrict__ hll_in, int my_nb, int c, uint32_t lds_wave)
 {
-    u32x4 ae = {0u, 0u, 0u, 0u}, ao = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int k = 0; k < kHllInFlight; ++k) {
-        ae.x = pk_max_u16(ae.x, h.x[k].x & 0x00FF00FFu); ao.x = pk_max_u16(ao.x, h.x[k].x & 0xFF00FF00u);
-        ae.y = pk_max_u16(ae.y, h.x[k].y & 0x00FF00FFu); ao.y = pk_max_u16(ao.y, h.x[k].y & 0xFF00FF00u);
-        ae.z = pk_max_u16(ae.z, h.x[k].z & 0x00FF00FFu); ao.z = pk_max_u16(ao.z, h.x[k].z & 0xFF00FF00u);
-        ae.w = pk_max_u16(ae.w, h.x[k].w & 0x00FF00FFu); ao.w = pk_max_u16(ao.w, h.x[k].w & 0xFF00FF00u);
+    if constexpr (T < kHllInFlight + kHllLds) {
+        const int nbt = __builtin_amdgcn_update_dpp(0, my_nb, 0x150 + T, 0xF, 0xF, false);
+        const int64_t j = T < h.deg ? (int64_t)nbt : h.i;
+        if (T < h.total)
+            __builtin_amdgcn_global_load_lds((global_u32 *)(uintptr_t)(hll_in + j * 256 + 16 * c),
+                                             (lds_u32 *)(uintptr_t)(lds_wave + 1024u * (T - kHllInFlight)), 16, 0, 0);
+        hll_post_lds<T + 1>(h, hll_in, my_nb, c, lds_wave);
     }
-    return u32x4{ae.x | ao.x, ae.y | ao.y, ae.z | ao.z, ae.w | ao.w};
+}
+
+__device__ __forceinline__ void hll_fold(const HllPosted &h, u32x4 &ae, u32x4 &ao)
+{
+#pragma unroll
+    for (int k = 0; k < kHllInFlight; ++k) hll_acc(ae, ao, h.x[k]);
 }
 
 // ---- the kernel: persistent, software-pipelined -------------------------------------------------------------------------------
@@ -88,10 +105,12 @@ __global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, 
 {
     constexpr int R = kFusedRows, kNb = kWave - R;
     __shared__ EstimatorLds lds;
+    __shared__ __attribute__((aligned(16))) uint8_t landing[256 / kWave][kHllLds > 0 ? kHllLds : 1][1024];
     const bool want_cards = cards_out != nullptr;
     EstimatorTables est = {};
     if (want_cards) est = stage_tables(lds, prm);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const uint32_t lds_wave = (uint32_t)(uintptr_t)&landing[wave][0][0];  // LDS byte address (low half of the generic pointer)
     const int64_t n_chunks = (g.rows() + R - 1) / R;
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x / kWave);
     int64_t chunk = (int64_t)blockIdx.x * (blockDim.x / kWave) + wave;
@@ -106,7 +125,9 @@ __global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, 
         return (nr > 0 && lane <= nr) ? g.rowptr[g.row0 + q * R + lane] : 0;
     };
     // what a lane fetches for a chunk whose bounds have arrived: its batch id (MinHash side) and its lane group's neighbour id (HLL side)
-    struct Ids { int64_t nid; int my_nb; };
+    // (nid stays 32 bits wide until it is used: widening it here would be a use of the load's result, and hipcc would wait
+    // -- vmcnt(0): for every HLL row posted just before -- right behind the load instead of after the MinHash walk)
+    struct Ids { int nid; int my_nb; };
     auto load_ids = [&](int64_t q, int64_t rp) -> Ids {
         const int nr = chunk_rows(q);
         if (nr == 0) return Ids{0, 0};
@@ -116,7 +137,8 @@ __global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, 
         const int c_n = __builtin_amdgcn_readlane(rel, nr);
         const int32_t *nb = g.col + c_lo;
         Ids out;
-        out.nid = lane >= kNb ? first + (lane - kNb) : (lane < c_n ? (int64_t)nb[lane] : 0);
+        out.nid = lane >= kNb ? (int)(first + (lane - kNb)) : 0;  // node ids are < 2^31 (checked by the entry point)
+        if (lane < kNb && lane < c_n) out.nid = nb[lane];
         const bool ok = grp < nr;
         const int rel0 = __shfl(rel, ok ? grp : 0), rel1 = __shfl(rel, ok ? grp + 1 : 0);
         out.my_nb = (ok && c < rel1 - rel0) ? nb[rel0 + c] : 0;
@@ -131,7 +153,7 @@ __global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, 
     for (; chunk < n_chunks; chunk += stride) {  // wave-uniform
         const int64_t first = g.row0 + chunk * R;
         m.begin(g, first, chunk_rows(chunk), rp_cur);
-        m.set_batch(ids_cur.nid);
+        m.set_batch((int64_t)ids_cur.nid);
         // HLL side of this chunk: the row of this lane group
         HllPosted h;
         const bool ok = grp < m.rows;
@@ -143,12 +165,27 @@ __global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, 
         h.write = ok && !hub;
         h.total = h.write ? h.deg + (h.i < m.n_self ? 1 : 0) : 0;
         hll_post<0>(h, hll_in, ids_cur.my_nb, c);              // HLL rows of chunk k
+        hll_post_lds<kHllInFlight>(h, hll_in, ids_cur.my_nb, c, lds_wave);
         const Ids ids_next = load_ids(chunk + stride, rp_next); // ids of chunk k + 1 (its bounds arrived during the last walk)
         const int64_t rp_after = load_bounds(chunk + 2 * stride);  // bounds of chunk k + 2
 #pragma unroll 1
         for (int r = 0; r < m.rows; ++r) m.row(r, mh_out);       // MinHash first hop of chunk k: VALU work under all of the above
-        const u32x4 acc = hll_fold(h);
-        hll_row16_finish(h.i, h.write, h.nb, h.deg, h.total, acc, kHllInFlight, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c);
+        u32x4 ae = {0u, 0u, 0u, 0u}, ao = {0u, 0u, 0u, 0u};
+        hll_fold(h, ae, ao);
+        if constexpr (kHllLds > 0) {
+            // (hll_fold waited for h.x; the LDS landings were issued after them and vmcnt retires in order -- but hipcc does not
+            // count a global_load_lds against the ds_read below, so the wait is spelled out; everything posted before the walk
+            // is long back by now)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < kHllLds; ++k) {
+                u32x4 v = *reinterpret_cast<const u32x4 *>(&landing[wave][k][16 * lane]);
+                if (!(kHllInFlight + k < h.total)) v = u32x4{0u, 0u, 0u, 0u};  // slot not written this round (stale bytes)
+                hll_acc(ae, ao, v);
+            }
+        }
+        const u32x4 acc = hll_acc_result(ae, ao);
+        hll_row16_finish(h.i, h.write, h.nb, h.deg, h.total, acc, kHllInFlight + kHllLds, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c);
         rp_cur = rp_next;
         rp_next = rp_after;
         ids_cur = ids_next;

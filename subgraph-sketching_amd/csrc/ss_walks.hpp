@@ -65,12 +65,9 @@ __device__ __forceinline__ u32x4 hll_walk(const uint8_t *__restrict__ hll_in, co
     for (int t = first; t < total; t += stride) {
         const int64_t j = t < deg ? (int64_t)nb[t] : self_row;
         const u32x4 x = *reinterpret_cast<const u32x4 *>(hll_in + j * M + 16 * c);
-        ae.x = pk_max_u16(ae.x, x.x & 0x00FF00FFu); ao.x = pk_max_u16(ao.x, x.x & 0xFF00FF00u);
-        ae.y = pk_max_u16(ae.y, x.y & 0x00FF00FFu); ao.y = pk_max_u16(ao.y, x.y & 0xFF00FF00u);
-        ae.z = pk_max_u16(ae.z, x.z & 0x00FF00FFu); ao.z = pk_max_u16(ao.z, x.z & 0xFF00FF00u);
-        ae.w = pk_max_u16(ae.w, x.w & 0x00FF00FFu); ao.w = pk_max_u16(ao.w, x.w & 0xFF00FF00u);
+        hll_acc(ae, ao, x);
     }
-    return u32x4{ae.x | ao.x, ae.y | ao.y, ae.z | ao.z, ae.w | ao.w};
+    return hll_acc_result(ae, ao);
 }
 
 // the first <= 16 neighbours of a row walked by ONE 16-lane DPP row: lane c fetches neighbour id c (one coalesced 64-byte
@@ -95,10 +92,7 @@ __device__ __forceinline__ void hll_visit16(const uint8_t *__restrict__ hll_in, 
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                ae.x = pk_max_u16(ae.x, x[k].x & 0x00FF00FFu); ao.x = pk_max_u16(ao.x, x[k].x & 0xFF00FF00u);
-                ae.y = pk_max_u16(ae.y, x[k].y & 0x00FF00FFu); ao.y = pk_max_u16(ao.y, x[k].y & 0xFF00FF00u);
-                ae.z = pk_max_u16(ae.z, x[k].z & 0x00FF00FFu); ao.z = pk_max_u16(ao.z, x[k].z & 0xFF00FF00u);
-                ae.w = pk_max_u16(ae.w, x[k].w & 0x00FF00FFu); ao.w = pk_max_u16(ao.w, x[k].w & 0xFF00FF00u);
+                hll_acc(ae, ao, x[k]);
             }
             hll_visit16<T0 + 4>(hll_in, my_nb, deg, count, self_row, c, ae, ao);
         }
@@ -112,7 +106,7 @@ __device__ __forceinline__ u32x4 hll_walk_first16(const uint8_t *__restrict__ hl
     const int my_nb = c < deg ? nb[c] : 0;
     u32x4 ae = {0u, 0u, 0u, 0u}, ao = {0u, 0u, 0u, 0u};
     hll_visit16<0>(hll_in, my_nb, deg, count, self_row, c, ae, ao);
-    return u32x4{ae.x | ao.x, ae.y | ao.y, ae.z | ao.z, ae.w | ao.w};
+    return hll_acc_result(ae, ao);
 }
 
 __device__ __forceinline__ uint32_t permuted_hash(uint64_t a, uint64_t b, uint64_t hv)
