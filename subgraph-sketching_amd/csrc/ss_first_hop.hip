@@ -157,8 +157,12 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
         rbs[r] = g.rowptr[i];
         degs[r] = (int)(g.rowptr[i + 1] - rbs[r]);
     }
+    // (unconditional loads from an address that is always valid -- lanes past the end of their row read the first word of
+    // rowptr and never look at it: a load under `if (l < deg)` is awaited with vmcnt(0) at the end of its branch, which put
+    // the four rows' id loads one round trip behind the other)
+    const int32_t *always_valid = reinterpret_cast<const int32_t *>(g.rowptr);
 #pragma unroll
-    for (int r = 0; r < kHllRows; ++r) nid0[r] = l < degs[r] ? g.col[rbs[r] + l] : -1;
+    for (int r = 0; r < kHllRows; ++r) nid0[r] = *(l < degs[r] ? g.col + rbs[r] + l : always_valid);
 #pragma unroll
     for (int r = 0; r < kHllRows; ++r) {
         const bool ok = oks[r];

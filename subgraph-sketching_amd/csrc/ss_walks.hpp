@@ -21,15 +21,33 @@ __host__ __device__ constexpr int pow2_ceil(int x)
     return p;
 }
 
+// The generic walks below take the neighbours t = first, first + stride, ... < total four at a time: four id loads, then four
+// row loads, then the four folds.  Two rules keep the loads of a batch in flight together (both learnt from the ISA): an id is
+// loaded UNCONDITIONALLY (lanes past the row's end read a word that always exists and ignore it) -- a load inside `if (t < deg)`
+// is awaited with vmcnt(0) at the end of its branch -- and nothing touches a loaded id (not even the widening to int64) before
+// every load of the batch is issued.  The plain `#pragma unroll 4` loop they replace cost two dependent round trips per neighbour.
+constexpr int kWalkBatch = 4;
+
 // min over the neighbours t = first, first + stride, ... < total of MinHash chunk c (16 bytes per lane)
 __device__ __forceinline__ u32x4 minhash_walk(const uint32_t *__restrict__ mh_in, const int32_t *__restrict__ nb, int deg, int total,
                                               int64_t self_row, int first, int stride, int P, int c)
 {
     u32x4 acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-#pragma unroll 4
-    for (int t = first; t < total; t += stride) {
-        const int64_t j = t < deg ? (int64_t)nb[t] : self_row;
-        acc = min4(acc, *reinterpret_cast<const u32x4 *>(mh_in + j * P + 4 * c));
+    const int32_t *always_valid = reinterpret_cast<const int32_t *>(mh_in);
+    for (int t = first; t < total; t += kWalkBatch * stride) {
+        int id[kWalkBatch];
+        u32x4 x[kWalkBatch];
+#pragma unroll
+        for (int k = 0; k < kWalkBatch; ++k) id[k] = *(t + k * stride < deg ? nb + t + k * stride : always_valid);
+#pragma unroll
+        for (int k = 0; k < kWalkBatch; ++k) {
+            const int tk = t + k * stride;
+            const int64_t j = tk < deg ? (int64_t)id[k] : self_row;
+            x[k] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (tk < total) x[k] = *reinterpret_cast<const u32x4 *>(mh_in + j * P + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < kWalkBatch; ++k) acc = min4(acc, x[k]);
     }
     return acc;
 }
@@ -61,11 +79,21 @@ __device__ __forceinline__ u32x4 hll_walk(const uint8_t *__restrict__ hll_in, co
                                           int64_t self_row, int first, int stride, int M, int c)
 {
     u32x4 ae = {0u, 0u, 0u, 0u}, ao = {0u, 0u, 0u, 0u};
-#pragma unroll 4
-    for (int t = first; t < total; t += stride) {
-        const int64_t j = t < deg ? (int64_t)nb[t] : self_row;
-        const u32x4 x = *reinterpret_cast<const u32x4 *>(hll_in + j * M + 16 * c);
-        hll_acc(ae, ao, x);
+    const int32_t *always_valid = reinterpret_cast<const int32_t *>(hll_in);
+    for (int t = first; t < total; t += kWalkBatch * stride) {
+        int id[kWalkBatch];
+        u32x4 x[kWalkBatch];
+#pragma unroll
+        for (int k = 0; k < kWalkBatch; ++k) id[k] = *(t + k * stride < deg ? nb + t + k * stride : always_valid);
+#pragma unroll
+        for (int k = 0; k < kWalkBatch; ++k) {
+            const int tk = t + k * stride;
+            const int64_t j = tk < deg ? (int64_t)id[k] : self_row;
+            x[k] = u32x4{0u, 0u, 0u, 0u};
+            if (tk < total) x[k] = *reinterpret_cast<const u32x4 *>(hll_in + j * M + 16 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < kWalkBatch; ++k) hll_acc(ae, ao, x[k]);
     }
     return hll_acc_result(ae, ao);
 }
