@@ -698,7 +698,11 @@ class HllPropagation(object):
 # ------------------------------------------------------------------------------------------------
 class ElphHashes(object):
     """class to store hashes and retrieve subgraph features (mirror of reference hashing.py:48-323)"""
-    FUSED_STAGE_MAX_TABLE_BYTES = 256 << 20  # ss_fused_hop_stage is used while the hop-1 HLL table fits the Infinity Cache
+    # largest hop-1 HLL table (bytes) ss_fused_hop_stage is used for.  The first version of the stage lost on tables that do not fit
+    # the 256 MiB Infinity Cache (citation2-like: 4.40 against 4.09 ms for the two launches) and was capped there; with LDS landings
+    # and batched tail walks it wins there too (3.70 against 3.92 ms), so there is no cap any more.  SS_FUSED_STAGE_MAX_MB:
+    # measurement hook
+    FUSED_STAGE_MAX_TABLE_BYTES = int(os.environ.get('SS_FUSED_STAGE_MAX_MB', str(1 << 30))) << 20
 
     def __init__(self, args):
         assert args.max_hash_hops in {1, 2, 3}, f'hashing is not implemented for {args.max_hash_hops} hops'
@@ -897,8 +901,7 @@ class ElphHashes(object):
             mh_prev = self._init_minhash_u32(num_nodes, device)  # hop 0 is replicated: a pure function of the node id
             hll_prev = self._init_hll_u8(num_nodes, device)
             table[0] = HopSketch(mh_prev, hll_prev, home)
-        # (only while the hop-1 HLL table the stage gathers from fits the 256 MiB Infinity Cache: collab-like -2 %, ppa-like -3 % per
-        # step; citation2-like, 750 MB of HBM-resident random gathers at the stage's 4 wavefronts per SIMD, +1.5 %)
+        # (collab-like -4 %, ppa-like -5 %, citation2-like -1.2 % per step against the unfused schedule)
         if (shard is None and fused and h >= 2 and self.num_perm == 128 and self.fuse_hop_stage
                 and num_nodes * self.m <= self.FUSED_STAGE_MAX_TABLE_BYTES):
             # ONE call for hops 1 and 2: hop-1 HLL first (hop-2 HLL rows need that table complete), then hop-1 MinHash + hop-2 HLL
