@@ -168,6 +168,31 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t x, uint32_
     return pre + inc - x;
 }
 
+// the same scan of the 256 key counters inside a workgroup of THREADS >= 256 threads: thread k < 256 owns key k, the other
+// wavefronts contribute zeros (tile sort / tile scatter run 512 threads per 4096-edge tile: 8 edges per thread)
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_exclusive_scan_keys(uint32_t x /* 0 for threads >= 256 */, uint32_t *wave_tot /* LDS [THREADS / 64] */,
+                                                              uint32_t *total)
+{
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    uint32_t inc = x;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == kWave - 1) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (int w = 0; w < kMaxKeys / kWave; ++w) {
+        if (w < wv) pre += wave_tot[w];
+        tot += wave_tot[w];
+    }
+    if (total) *total = tot;
+    __syncthreads();
+    return pre + inc - x;
+}
+
 // where a workgroup's edges come from and how they are keyed
 struct PassArgs {
     const int64_t *src, *dst;            // pass 1 input: slices of the caller's edge list
@@ -316,27 +341,30 @@ __global__ __launch_bounds__(kThreads) void scan_sub_counts_kernel(uint32_t *__r
 }
 
 // tile-sorted scatter: every 4096-edge tile is ordered by key in LDS, then written as contiguous runs
+constexpr int kScatterThreads = 512;  // 8 edges per thread and tile (256 x 16: ppa-like pass 1 / pass 2 293 / 201 us)
+
 template <bool PASS2>
-__global__ __launch_bounds__(kThreads) void scatter_tiles_kernel(PassArgs a, const uint32_t *__restrict__ offsets,
+__global__ __launch_bounds__(kScatterThreads) void scatter_tiles_kernel(PassArgs a, const uint32_t *__restrict__ offsets,
                                                                  const unsigned long long *__restrict__ key_base, int2 *__restrict__ out,
                                                                  unsigned long long *__restrict__ n_self, int32_t *__restrict__ err)
 {
     __shared__ int2 sorted[kTile];
-    __shared__ uint32_t tile_hist[kMaxKeys], tile_off[kMaxKeys], wave_tot[kThreads / kWave];
+    __shared__ uint32_t tile_hist[kMaxKeys], tile_off[kMaxKeys], wave_tot[kScatterThreads / kWave];
     __shared__ unsigned long long cursor[kMaxKeys];
     __shared__ unsigned long long block_max;
     int64_t lo, hi;
     int group, part, parts;
     block_range<PASS2>(a, lo, hi, group, part, parts);
-    cursor[threadIdx.x] = 0;
+    const bool key_owner = threadIdx.x < kMaxKeys;  // thread k < 256 owns key k
+    if (key_owner) cursor[threadIdx.x] = 0;
     if ((int)threadIdx.x < a.keys) {
         const uint32_t off = offsets[((int64_t)group * a.keys + threadIdx.x) * parts + part];
         cursor[threadIdx.x] = PASS2 ? a.seg_base[group] + off : key_base[threadIdx.x] + off;
     }
-    tile_hist[threadIdx.x] = 0;
+    if (key_owner) tile_hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) block_max = 0;
     __syncthreads();
-    constexpr int PER = kTile / kThreads;  // 16 edges per thread and tile
+    constexpr int PER = kTile / kScatterThreads;  // 8 edges per thread and tile
     int64_t my_max = -1;
     bool bad = false;
     for (int64_t t0 = lo; t0 < hi; t0 += kTile) {
@@ -345,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void scatter_tiles_kernel(PassArgs a, con
         uint32_t rank[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int64_t e = t0 + threadIdx.x + (int64_t)k * kThreads;
+            const int64_t e = t0 + threadIdx.x + (int64_t)k * kScatterThreads;
             key[k] = -1;
             ed[k] = make_int2(0, 0);
             if (e < hi) {
@@ -370,21 +398,23 @@ __global__ __launch_bounds__(kThreads) void scatter_tiles_kernel(PassArgs a, con
         for (int k = 0; k < PER; ++k) rank[k] = key[k] >= 0 ? atomicAdd(&tile_hist[key[k]], 1u) : 0u;
         __syncthreads();
         uint32_t tile_n = 0;
-        const uint32_t ex = block_exclusive_scan_256(tile_hist[threadIdx.x], wave_tot, &tile_n);
-        tile_off[threadIdx.x] = ex;
+        const uint32_t ex = block_exclusive_scan_keys<kScatterThreads>(key_owner ? tile_hist[threadIdx.x] : 0u, wave_tot, &tile_n);
+        if (key_owner) tile_off[threadIdx.x] = ex;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER; ++k)
             if (key[k] >= 0) sorted[tile_off[key[k]] + rank[k]] = ed[k];
         __syncthreads();
-        for (uint32_t q = threadIdx.x; q < tile_n; q += kThreads) {
+        for (uint32_t q = threadIdx.x; q < tile_n; q += kScatterThreads) {
             const int2 v = sorted[q];
             const int kq = key_of<PASS2>(a, (int64_t)v.y, group);
             out[cursor[kq] + (q - tile_off[kq])] = v;
         }
         __syncthreads();
-        cursor[threadIdx.x] += tile_hist[threadIdx.x];
-        tile_hist[threadIdx.x] = 0;
+        if (key_owner) {
+            cursor[threadIdx.x] += tile_hist[threadIdx.x];
+            tile_hist[threadIdx.x] = 0;
+        }
         __syncthreads();
     }
     if (!PASS2) {
@@ -640,22 +670,9 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
     for (int k = 0; k < PER; ++k) rank[k] = key[k] >= 0 ? atomicAdd(&tile_hist[key[k]], 1u) : 0u;
     __syncthreads();
     // exclusive scan of the <= 256 key counts: thread k < 256 owns key k, the other wavefronts contribute zeros
-    const uint32_t mine = threadIdx.x < kMaxKeys ? tile_hist[threadIdx.x] : 0u;
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    uint32_t inc = mine;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-    }
-    if (lane == kWave - 1) wave_tot[wv] = inc;
-    __syncthreads();
-    uint32_t pre = 0, tile_n = 0;
-    for (int w = 0; w < kMaxKeys / kWave; ++w) {
-        if (w < wv) pre += wave_tot[w];
-        tile_n += wave_tot[w];
-    }
-    const uint32_t ex = pre + inc - mine;
+    uint32_t tile_n = 0;
+    const uint32_t ex = block_exclusive_scan_keys<kSortThreads>(threadIdx.x < kMaxKeys ? tile_hist[threadIdx.x] : 0u, wave_tot, &tile_n);
+    const int lane = threadIdx.x & (kWave - 1);
     if (threadIdx.x < kMaxKeys) tile_offs[threadIdx.x] = ex;
     __syncthreads();
 #pragma unroll
@@ -798,7 +815,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_bases_kernel, dim3(1), dim3(kThreads), 0, stream, w.base1, p.keys1, rowptr, N);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scatter_tiles_kernel<false>, dim3(p.blocks1), dim3(kThreads), 0, stream, a1, w.counts1, w.base1, w.staged_a, n_self,
+    hipLaunchKernelGGL(scatter_tiles_kernel<false>, dim3(p.blocks1), dim3(kScatterThreads), 0, stream, a1, w.counts1, w.base1, w.staged_a, n_self,
                        err_flag);
     SS_LAUNCH_CHECK();
     const int2 *final_staged = w.staged_a;
@@ -816,7 +833,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
         hipLaunchKernelGGL(scan_sub_counts_kernel, dim3(p.keys1), dim3(kThreads), 0, stream, w.counts2, p.keys2, p.parts2, w.base1,
                            w.fine_base, buckets2, p.keys1);
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks2), dim3(kThreads), 0, stream, a2, w.counts2, w.base1, w.staged_b,
+        hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks2), dim3(kScatterThreads), 0, stream, a2, w.counts2, w.base1, w.staged_b,
                            (unsigned long long *)nullptr, (int32_t *)nullptr);
         SS_LAUNCH_CHECK();
         final_staged = w.staged_b;
@@ -834,7 +851,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
             hipLaunchKernelGGL(scan_sub_counts_kernel, dim3((unsigned)p.groups3), dim3(kThreads), 0, stream, w.counts3, p.keys3, p.parts3,
                                w.fine_base, w.fine_base3, p.fine_buckets, (int)p.groups3);
             SS_LAUNCH_CHECK();
-            hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks3), dim3(kThreads), 0, stream, a3, w.counts3, w.fine_base, w.staged_a,
+            hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks3), dim3(kScatterThreads), 0, stream, a3, w.counts3, w.fine_base, w.staged_a,
                                (unsigned long long *)nullptr, (int32_t *)nullptr);
             SS_LAUNCH_CHECK();
             final_staged = w.staged_a;
