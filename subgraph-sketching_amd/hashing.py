@@ -953,7 +953,11 @@ class ElphHashes(object):
             cards = cards[:num_nodes]
         for k in range(1, h + 1):
             table[k] = HopSketch(mh[k - 1][:num_nodes], hll[k - 1][:num_nodes], home)
-        return table, _stamp_tables(cards if home == device else cards.to(home), self.tables_id)
+        if home != device:
+            cards = cards.to(home)
+            if self.strict_bounds == 'deferred':  # (the copy has waited for the build: the report is final, see get_subgraph_features)
+                self._deferred.raise_if_set()
+        return table, _stamp_tables(cards, self.tables_id)
 
     def _first_hop(self, csr, device, mh_out, hll_out, cards, params, rows=None):
         """fused hop-0 + hop-1 (ss_first_hop) for either or both sketches"""
@@ -1147,4 +1151,11 @@ class ElphHashes(object):
             chunks = [self._pair_kernel(links[s:s + batch_size], hash_table, cards, degrees=degrees)[0]
                       for s in range(0, n, batch_size)]
             feats = torch.cat(chunks, dim=0)
-        return feats if feats.device == links.device else feats.to(links.device)
+        if feats.device == links.device:
+            return feats
+        out = feats.to(links.device)
+        # links on another device (BUDDY keeps them on the CPU): the copy back has waited for the launches, so the deferred
+        # bounds report is final and can be raised from the offending call itself -- as the reference's CPU indexing does
+        if self.strict_bounds == 'deferred':
+            self._deferred.raise_if_set()
+        return out
