@@ -231,8 +231,9 @@ extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, 
     }
     constexpr int rows_per_block = 4 * kFusedRows;
     const unsigned blocks = (unsigned)((g.rows() + rows_per_block - 1) / rows_per_block);
-    // 4 workgroups are resident per CU (128 VGPRs); twice that many balance the tail (165.9 against 169.9 us on the bench graph)
-    static const int wg_per_cu = getenv("SS_FUSED_WG_PER_CU") ? atoi(getenv("SS_FUSED_WG_PER_CU")) : 8;
+    // 4 workgroups are resident per CU (126 VGPRs); three times that many balance the tail (bench graph: 4 / 8 / 12 / 16 / all
+    // 14 742 workgroups: 158.7 / 153-157 / 150-153 / 153.5 / 163 us)
+    static const int wg_per_cu = getenv("SS_FUSED_WG_PER_CU") ? atoi(getenv("SS_FUSED_WG_PER_CU")) : 12;
     const unsigned grid = blocks < (unsigned)(256 * wg_per_cu) ? blocks : (unsigned)(256 * wg_per_cu);
     {
         ProfileSpan span(s, SS_PROF_FUSED);
