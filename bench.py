@@ -253,7 +253,11 @@ def main():
 
     for _ in range(a.warmup):
         feats = step()
-    lib.ss_profile_enable(1 << nat.PROF_MINHASH_HOP)  # HIP events around every launch of the dominant kernel, on its stream
+    # HIP events around every launch of the dominant kernel, on its stream.  ELPH call sequence at h = 2 with the deferred table hop:
+    # no full MinHash table hop is left in a step (the query's rows go through ss_minhash_hop_rows) -- the fused stage dominates
+    elph_rows_only = a.api == 'elph' and ssa.hashing.DEFER_TABLE_HOP and ssa.hashing.LAZY_MINHASH
+    dom_tag = nat.PROF_FUSED if (elph_rows_only and h == 2) else nat.PROF_MINHASH_HOP
+    lib.ss_profile_enable(1 << dom_tag)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -261,7 +265,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     dom_ms, dom_n = c_float(), c_int32()
-    lib.ss_profile_read(nat.PROF_MINHASH_HOP, byref(dom_ms), byref(dom_n))  # the launches of the timed region only
+    lib.ss_profile_read(dom_tag, byref(dom_ms), byref(dom_n))  # the launches of the timed region only
     lib.ss_profile_enable(0)
     if launched:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -287,7 +291,7 @@ def main():
     kernel_table = None
     if not a.no_kernel_table:
         tags = {'csr_build': nat.PROF_CSR, 'first_hop_hll': nat.PROF_FIRST_HOP_HLL, 'first_hop_minhash': nat.PROF_FIRST_HOP_MH,
-                'hll_hop': nat.PROF_HLL_HOP, 'fused_first_hop_hll_hop': nat.PROF_FUSED, 'minhash_hop': nat.PROF_MINHASH_HOP, 'hub_passes': nat.PROF_HUB,
+                'hll_hop': nat.PROF_HLL_HOP, 'fused_first_hop_hll_hop': nat.PROF_FUSED, 'minhash_hop': nat.PROF_MINHASH_HOP, 'minhash_hop_rows': nat.PROF_MINHASH_ROWS, 'hub_passes': nat.PROF_HUB,
                 'pair_features': nat.PROF_PAIRS}
         lib.ss_profile_enable(sum(1 << t for t in tags.values()))
         extra = 5
@@ -296,6 +300,7 @@ def main():
         fence()
         lib.ss_profile_enable(0)
         model = rf.kernel_bytes(n, e_dir, P, HLL_P, h, min(links.size(0), batch))
+        model['minhash_hop_rows'] = rf.minhash_rows_bytes(n, e_dir, 2 * min(links.size(0), batch), P)
         kernel_table = {}
         for name, tag in tags.items():
             ms, cnt = c_float(), c_int32()
@@ -313,6 +318,10 @@ def main():
     # ---- roofline of the dominant kernel -----------------------------------------------------------------------------
     prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch)['minhash_hop']
     roof_kernel = "ss::propagate_kernel<128,256> (MinHash table hop: (E'+N)*4P + 4E + 8(N+1) bytes)"
+    if dom_tag == nat.PROF_FUSED:
+        prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch)['fused_first_hop_hll_hop']
+        roof_kernel = ("ss::fused_hop_persistent_kernel<2> (MinHash first hop + HLL table hop: 4E + 8(N+1) + N*4P + (E'+N)*M + 4N bytes; "
+                       "VALU-bound first hop over the memory-bound table hop)")
     if sharded_build:  # each launch covers this rank's N/G destination rows and (on the uniform graph) E'/G in-edges
         prop_bytes //= world
         roof_kernel += f' / {world} ranks (row-sharded build)'
@@ -336,7 +345,9 @@ def main():
         'vs_baseline': None, 'dtype': 'u32/u8 sketches, f32 estimator', 'data': 'synthetic',
         'config': {'workload': f'ogbl-{a.config}-like synthetic {a.graph} graph' + (' (BASELINE configs[1])' if a.config == 'collab' else '') +
                                ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps' +
-                               ('' if a.api == 'build_query' else f' [api mode: {a.api}' + (f', {buddy_batches} batches of {batch} pairs per build' if a.api == 'buddy' else '') + ']'),
+                               ('' if a.api == 'build_query' else f' [api mode: {a.api}' + (f', {buddy_batches} batches of {batch} pairs per build' if a.api == 'buddy' else '')
+                                + (', last-hop MinHash rows computed for the queried nodes only (hashing.DEFER_TABLE_HOP; SS_DEFER_TABLE_HOP=0: all N rows)'
+                                   if a.api == 'elph' and ssa.hashing.DEFER_TABLE_HOP else '') + ']'),
                    'num_nodes': n, 'directed_edges': e_dir, 'max_hash_hops': h, 'minhash_num_perm': P, 'hll_p': HLL_P,
                    'pairs_per_step_per_gpu': links.size(0), 'global_pairs_per_step': pairs_per_step,
                    'parallelism': (f'edge batches sharded x{world} ({a.scaling} scaling), all_gather of features; sketch table ' +
@@ -344,12 +355,13 @@ def main():
                                     else 'replicated (every rank builds it)')),
                    'hll_tables': eh.tables_id},
         'roofline': {'kernel': roof_kernel + ('' if h > 1 else ' (not launched at h=1)') +
-                               (' [elph api mode launches it per sketch: the same kernel and bytes]' if a.api == 'elph' else ''),
+                               (' [elph api mode launches it per sketch: the same kernel and bytes]' if a.api == 'elph' and dom_tag != nat.PROF_FUSED else ''),
                      'bound': 'hbm', 'achieved': achieved, 'peak': rf.HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / rf.HBM_PEAK_GBS if achieved else None, 'traffic': None, 'traffic_profiled': profiled,
                      'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n,
-                     'resident': rf.residency(n, 'minhash_hop', P, HLL_P),
-                     'unique_hbm_bytes_per_launch': rf.unique_bytes(n, e_dir, 'minhash_hop', P, HLL_P) // (world if sharded_build else 1),
+                     'resident': rf.residency(n, 'hll_hop' if dom_tag == nat.PROF_FUSED else 'minhash_hop', P, HLL_P),
+                     'unique_hbm_bytes_per_launch': (rf.unique_bytes(n, e_dir, 'hll_hop', P, HLL_P) + n * 4 * P if dom_tag == nat.PROF_FUSED else
+                                                     rf.unique_bytes(n, e_dir, 'minhash_hop', P, HLL_P) // (world if sharded_build else 1)),
                      'note': 'resident = infinity-cache: the gathered table (N*4P bytes) fits the 256 MiB Infinity Cache, so `achieved` is a '
                              'fabric + cache rate and may exceed what HBM alone streams (~6.3 TB/s); see --config citation2 for the HBM-resident case'},
     }

@@ -126,6 +126,16 @@ int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_
                  const uint8_t *hll_in, uint8_t *hll_out, int32_t M,
                  float *cards_out, int64_t cards_stride, const ss_hll_params *prm, void *stream);
 
+/* The MinHash half of ss_propagate for a LIST of destination rows: mh_out[r] = min over the in-neighbours of r (and r itself,
+ * as above) for every r in rows[0 .. n_rows) -- ids may repeat, negative ids count from the end (torch indexing), ids outside
+ * [-N, N) are ignored -- plus every hub row of the graph (the cooperative hub pass always serves all of them); all other rows
+ * of mh_out are left untouched.  For the caller whose next step reads only a few rows of the hop's table: ELPH's training
+ * step (models/elph.py:209-212 followed by runners/train.py:204) propagates over the whole graph and then queries two rows
+ * per link of ONE batch; the host mirror defers the last minhash_prop (hashing.py:28-35) and computes the batch's rows
+ * through this entry point -- same values, 2 B instead of N rows. */
+int ss_minhash_hop_rows(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_out, int32_t P, const int64_t *rows,
+                        int64_t n_rows, void *stream);
+
 /* Hop 1 straight from node ids: equivalent to ss_minhash_init + ss_hll_init + one ss_propagate
  * (hashing.py:118-137, 28-45 at k = 1, 163) but the hop-0 rows -- pure functions of the node id -- are
  * recomputed in registers instead of being written to and re-read from HBM.  a / b: device uint64[P].

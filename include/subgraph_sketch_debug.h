@@ -28,7 +28,8 @@ extern "C" {
 #define SS_PROF_CSR 5             /* all launches of one ss_csr_build                                                    */
 #define SS_PROF_HUB 6             /* hub / mega-row passes (propagate_hub_kernel, first_hop_hub_kernel)                  */
 #define SS_PROF_FUSED 7           /* ss::fused_hop_persistent_kernel (MinHash first hop + HLL table hop in one launch)     */
-#define SS_PROF_TAGS 8
+#define SS_PROF_MINHASH_ROWS 8    /* ss_minhash_hop_rows: the MinHash table hop of a list of rows                          */
+#define SS_PROF_TAGS 9
 int ss_profile_enable(uint32_t tag_mask);   /* bit t enables family t; 0 disables everything */
 int ss_profile_read(int32_t tag, float *mean_ms_out, int32_t *launches_out);
 

@@ -31,8 +31,8 @@ class CsrGraphStruct(ctypes.Structure):
                 ('mega_scratch', c_void_p), ('row_begin', c_int64), ('row_end', c_int64)]
 
 
-ABI_VERSION = 122  # ss_version() of the library this module's struct mirrors and signatures describe
-PROF_MINHASH_HOP, PROF_HLL_HOP, PROF_FIRST_HOP_MH, PROF_FIRST_HOP_HLL, PROF_PAIRS, PROF_CSR, PROF_HUB, PROF_FUSED = range(8)  # SS_PROF_* tags
+ABI_VERSION = 123  # ss_version() of the library this module's struct mirrors and signatures describe
+PROF_MINHASH_HOP, PROF_HLL_HOP, PROF_FIRST_HOP_MH, PROF_FIRST_HOP_HLL, PROF_PAIRS, PROF_CSR, PROF_HUB, PROF_FUSED, PROF_MINHASH_ROWS = range(9)  # SS_PROF_* tags
 MEGA_SLICE, MEGA_SLOT_BYTES = 4096, 1280  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
 
 
@@ -47,6 +47,7 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ss_propagate': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p]),
+    'ss_minhash_hop_rows': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     'ss_first_hop': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p, c_int32,
                                c_void_p, c_void_p, c_int64, POINTER(HllParams), c_void_p]),
     'ss_fused_hop_stage': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,

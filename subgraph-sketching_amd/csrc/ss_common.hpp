@@ -270,6 +270,10 @@ struct GraphArgs {  // device-side view of ss_csr_graph
     const int32_t *mega_count;  // {mega rows, slices}
     uint8_t *mega_scratch;      // kMegaSlot bytes per slice: partial MinHash row at 0, partial HLL row at kMegaHllOffset
     int64_t row0, row1;  // destination rows [row0, row1) are computed by this launch
+    // ss_minhash_hop_rows: the launch computes the rows listed here instead (n_list entries, torch-style negative ids allowed,
+    // out-of-range ids ignored, duplicates harmless); nullptr for every other launch
+    const int64_t *row_list = nullptr;
+    int64_t n_list = 0;
     __host__ __device__ int64_t rows() const { return row1 - row0; }
     __device__ bool owns(int64_t i) const { return i >= row0 && i < row1; }
 };

@@ -34,8 +34,16 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
     const int M = TM ? TM : M_rt;
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform row id (readfirstlane makes the uniformity visible to the compiler: scalar loads, scalar loop control)
-    const int64_t i = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    if (i >= g.row1) return;
+    int64_t i = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    if (g.row_list) {  // ss_minhash_hop_rows: the q-th wavefront computes row row_list[q]
+        const int64_t q = i - g.row0;
+        if (q >= g.n_list) return;
+        i = g.row_list[q];
+        i = i < 0 ? i + g.N : i;
+        if ((uint64_t)i >= (uint64_t)g.N) return;  // the query kernel reports such ids; nothing to compute here
+    } else if (i >= g.row1) {
+        return;
+    }
 
     const int64_t rb = g.rowptr[i];
     const int deg = (int)(g.rowptr[i + 1] - rb);
@@ -309,6 +317,39 @@ int launch_propagate_hub_only(const GraphArgs &g, const uint32_t *mh_in, uint32_
 }
 
 }  // namespace ss
+
+// MinHash table hop of the listed rows only (+ the hub pass, which always serves every hub row)
+extern "C" int ss_minhash_hop_rows(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_out, int32_t P, const int64_t *rows,
+                                   int64_t n_rows, void *stream)
+{
+    using namespace ss;
+    if (!graph || graph->num_nodes < 0 || !graph->rowptr || !mh_in || !mh_out || n_rows < 0 || (n_rows > 0 && !rows)) return SS_ERR_INVALID_ARG;
+    if (P <= 0 || (P & 3) || P > 2048) return SS_ERR_INVALID_ARG;
+    const int64_t N = graph->num_nodes;
+    if (N == 0 || n_rows == 0) return SS_OK;
+    if (N >= ((int64_t)1 << 31) || n_rows >= ((int64_t)1 << 33)) return SS_ERR_INVALID_ARG;
+    if ((graph->hub_rows == nullptr) != (graph->hub_count == nullptr)) return SS_ERR_INVALID_ARG;
+    if (graph->row_begin != 0 || graph->row_end != 0) return SS_ERR_INVALID_ARG;  // a row list and a row range exclude each other
+    GraphArgs g = to_args(*graph);
+    g.row_list = rows;
+    g.n_list = n_rows;
+    hipStream_t s = (hipStream_t)stream;
+    const bool hubs = P == 128 && g.hub_rows && g.hub_count;  // (the hub pass of the table hops is P = 128 only, as in ss_propagate)
+    const unsigned blocks = (unsigned)((n_rows + 3) / 4);
+    {
+        ProfileSpan span(s, SS_PROF_MINHASH_ROWS);
+        if (P == 128)
+            hipLaunchKernelGGL((propagate_kernel<128, 256>), dim3(blocks), dim3(256), 0, s, g, mh_in, mh_out, 128, (const uint8_t *)nullptr,
+                               (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, ss_hll_params{}, hubs);
+        else
+            hipLaunchKernelGGL((propagate_kernel<0, 0>), dim3(blocks), dim3(256), 0, s, g, mh_in, mh_out, P, (const uint8_t *)nullptr,
+                               (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, ss_hll_params{}, false);
+    }
+    SS_LAUNCH_CHECK();
+    if (!hubs) return SS_OK;
+    GraphArgs all = to_args(*graph);
+    return launch_propagate_hub_only(all, mh_in, mh_out, nullptr, nullptr, nullptr, 0, ss_hll_params{}, s);
+}
 
 extern "C" int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_out, int32_t P,
                             const uint8_t *hll_in, uint8_t *hll_out, int32_t M,

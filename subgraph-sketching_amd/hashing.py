@@ -320,6 +320,12 @@ LAZY_MINHASH = True  # minhash_prop returns its int64 result as a LazyMinhash (m
 # memory-bound table hop).  Anything else that needs the table first (the next minhash_prop, get_subgraph_features, any torch
 # operator on the tensor) triggers the ordinary first-hop launch.  Same results either way.
 DEFER_FIRST_HOP = os.environ.get('SS_FUSED_STAGE', '1') != '0'
+# Deferred table hop: `minhash_prop` on any other input only RECORDS the hop as well.  The next consumer decides how much of it is
+# computed: another `minhash_prop` (or any torch operator, torch.save ...) needs the whole table; `get_subgraph_features` reads two
+# rows per link, and ELPH's training step (models/elph.py:209-212, runners/train.py:204) queries ONE batch after every full-graph
+# propagation -- the rows of that batch are computed through ss_minhash_hop_rows (2 B rows instead of N; same values) and the
+# table stays owed for everybody else.  Batches on the same table whose rows add up to more than N make it complete instead.
+DEFER_TABLE_HOP = os.environ.get('SS_DEFER_TABLE_HOP', '1') != '0'
 
 
 class LazyMinhash(torch.Tensor):
@@ -335,18 +341,19 @@ class LazyMinhash(torch.Tensor):
     __torch_function__ = torch._C._disabled_torch_function_impl
 
     @staticmethod
-    def __new__(cls, packed, pending=None):
+    def __new__(cls, packed, pending=None, partial=None):
         return torch.Tensor._make_wrapper_subclass(cls, packed.shape, dtype=torch.int64, device=packed.device, requires_grad=False)
 
-    def __init__(self, packed, pending=None):
-        """pending: a zero-argument callable that FILLS `packed` (deferred first hop, see MinhashPropagation.forward); it is
-        run the first time the table is needed -- or never, when HllPropagation computes the table on the way (fused stage)"""
-        self._packed, self._real, self._pending = packed, None, pending
+    def __init__(self, packed, pending=None, partial=None):
+        """pending: a zero-argument callable that FILLS `packed` (deferred hop, see MinhashPropagation.forward); it is
+        run the first time the table is needed -- or never, when HllPropagation computes the table on the way (fused stage).
+        partial: optional callable(rows int64 [n]) that fills THOSE rows of `packed` only (DEFER_TABLE_HOP)"""
+        self._packed, self._real, self._pending, self._partial, self._partial_rows = packed, None, pending, partial, 0
 
     def resolve(self):
         """run the deferred computation of the packed table, if there is one"""
         if self._pending is not None:
-            fill, self._pending = self._pending, None
+            fill, self._pending, self._partial = self._pending, None, None
             fill()
 
     def materialise(self):
@@ -355,6 +362,18 @@ class LazyMinhash(torch.Tensor):
             self._real = unpack_minhash(self._packed)
             self._packed = None
         return self._real
+
+    def packed_for_rows(self, rows):
+        """the packed table with at least `rows` (int64 node ids, any shape) computed, for a reader of those rows alone"""
+        if self._real is not None:
+            return None
+        if self._pending is not None and self._partial is not None:
+            if self._partial_rows + rows.numel() <= self._packed.size(0):
+                self._partial_rows += rows.numel()
+                self._partial(rows.reshape(-1))
+                return self._packed
+        self.resolve()
+        return self._packed
 
     def packed_if_valid(self):
         """the packed table while nothing outside the engine has seen (and possibly edited) the int64 form"""
@@ -629,7 +648,20 @@ class MinhashPropagation(object):
             if not _first_hop_from_ids(csr, device, hop0[0], x.size(1), hop0[1], out_u32, None):
                 out_u32 = None
         if out_u32 is None:
-            out_u32, _ = _propagate(csr, _packed_minhash_of(x, device), None, device)
+            mh_in = _packed_minhash_of(x, device)
+            if DEFER_TABLE_HOP and LAZY_MINHASH and x.device == device:
+                out_u32 = torch.empty_like(mh_in)
+
+                def fill(csr=csr, mh_in=mh_in, out=out_u32, device=device):
+                    _propagate(csr, mh_in, None, device, mh_out=out)
+
+                def fill_rows(rows, csr=csr, mh_in=mh_in, out=out_u32, device=device):
+                    graph = csr.struct()
+                    with _Span('propagate_mh_rows', device):
+                        _native.check(_native.lib().ss_minhash_hop_rows(byref(graph), _ptr(mh_in), _ptr(out), mh_in.size(1), _ptr(rows),
+                                                                        rows.numel(), _stream(device)), 'ss_minhash_hop_rows')
+                return LazyMinhash(out_u32, pending=fill, partial=fill_rows)
+            out_u32, _ = _propagate(csr, mh_in, None, device)
         if LAZY_MINHASH and x.device == device:
             return LazyMinhash(out_u32)
         out = unpack_minhash(out_u32)
@@ -969,7 +1001,9 @@ class ElphHashes(object):
                                                      byref(params.struct), _stream(device)), 'ss_first_hop')
 
     # ---- query ---------------------------------------------------------------------------------------
-    def _resolve_tables(self, hash_table, device):
+    def _resolve_tables(self, hash_table, device, rows=None):
+        """packed tables of hops 1 .. max_hops; rows: the node ids the caller is going to read (a deferred LAST hop -- nobody
+        else's input -- is then computed for those rows only, DEFER_TABLE_HOP)"""
         mh, hll = [], []
         for k in range(1, self.max_hops + 1):
             entry = hash_table[k]
@@ -978,7 +1012,11 @@ class ElphHashes(object):
                 mh.append(m)
                 hll.append(l)
             else:
-                mh.append(_packed_minhash_of(entry['minhash'], device))
+                t = entry['minhash']
+                tw = None
+                if rows is not None and k == self.max_hops and isinstance(t, LazyMinhash) and t.device == device:
+                    tw = t.packed_for_rows(rows)
+                mh.append(tw if tw is not None else _packed_minhash_of(t, device))
                 hll.append(_packed_hll_of(entry['hll'], device))
         N, P = mh[0].shape
         for a, b in zip(mh, hll):
@@ -992,9 +1030,9 @@ class ElphHashes(object):
         first = hash_table.get(1) if hasattr(hash_table, 'get') else None
         device = _compute_device(links, first.mh_u32 if isinstance(first, HopSketch) else None, cards)
         params = self._params(device)
-        mh, hll, N, P = self._resolve_tables(hash_table, device)
-        h = self.max_hops
         lk = links.to(device=device, dtype=torch.int64).contiguous()
+        mh, hll, N, P = self._resolve_tables(hash_table, device, rows=lk)
+        h = self.max_hops
         B = lk.size(0)
         if cards is None:
             cd = torch.zeros((N, h), dtype=torch.float32, device=device)

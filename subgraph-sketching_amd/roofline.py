@@ -42,6 +42,12 @@ def kernel_bytes(N, E, P=128, p=8, h=2, B=65536):
     }
 
 
+def minhash_rows_bytes(N, E, n_rows, P=128):
+    """ss_minhash_hop_rows over n_rows rows drawn uniformly: per row its (E/N + 1) neighbour rows (self loop included) and its own
+    output row of 4P bytes, its col entries and two rowptr words, the int64 row id"""
+    return int(n_rows * ((E / N + 2) * 4 * P + 4 * E / N + 16 + 8))
+
+
 def pair_bytes(P=128, p=8, h=2):
     """per pair: 2h sketch rows + the two int64 ids + 2h cardinalities + h(h+2) fp32 features"""
     return 2 * h * (4 * P + (1 << p)) + 16 + 8 * h + 4 * h * (h + 2)

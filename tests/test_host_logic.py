@@ -260,6 +260,10 @@ def test_byte_model_of_the_step(ssa):
     assert rf.residency(576289, 'minhash_hop') == 'hbm' and rf.residency(576289, 'hll_hop') == 'infinity-cache'
     assert rf.unique_bytes(n, e, 'minhash_hop') == 2 * n * 512 + 4 * e + 8 * (n + 1)
     assert rf.csr_bytes(n, e) == 52 * e + 8 * (n + 1) and rf.csr_bytes(576289, e) == 76 * e + 8 * 576290
+    # ss_minhash_hop_rows over all N rows moves what the full table hop moves (+ an 8-byte row id and a second rowptr word per
+    # listed row), over one ELPH batch 1.7 % of it
+    assert abs(rf.minhash_rows_bytes(n, e, n) - (k['minhash_hop'] + 16 * n)) < 1e5
+    assert abs(rf.minhash_rows_bytes(n, e, 4096) / k['minhash_hop'] - 4096 / n) < 1e-3
 
 
 def test_batch_plan_bookkeeping(ssa):
