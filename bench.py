@@ -17,8 +17,8 @@ N > 1    : one process per GPU (torchrun), per-batch feature rows all-gathered o
            --scaling strong: ONE global batch of B pairs (BASELINE configs[3] / [4] are fixed global batches sharded across
                8 GPUs), rank r computes its contiguous slice; with --build sharded the destination rows of every hop are
                split across the ranks too (in-place all-gather per hop and sketch).  value(N) / value(1) = speed-up.
-           --api buddy: one build, then --buddy-links pairs in batches of B (datasets/elph.py:200-208); strong scaling
-               shards every batch.
+           --api buddy: one build, then --buddy-links pairs in chunks of --buddy-chunk (the reference's subgraph_feature_batch_size,
+               11 M: datasets/elph.py:200-208); strong scaling shards the link set.
 roofline : the dominant kernel = ss::propagate_kernel<128,256>, the MinHash table hop.  achieved = algorithmic bytes per
            launch ((E'+N)*4P + 4E + 8(N+1), subgraph_sketching_amd/roofline.py) / mean launch duration measured live in
            the timed region with HIP events recorded INSIDE the library on the launch stream (subgraph_sketch_debug.h).
@@ -142,6 +142,9 @@ def main():
                     help='build_query (default, the BASELINE metric): build_hash_tables + get_subgraph_features per step; '
                          'elph: the exact call sequence of ELPH.forward (models/elph.py:186-213) + one query per step; '
                          'buddy: one build amortised over --buddy-links pairs (datasets/elph.py:200-208)')
+    ap.add_argument('--buddy-chunk', type=int, default=11000000,
+                    help='pairs per get_subgraph_features launch in --api buddy (default: the reference\'s --subgraph_feature_batch_size, '
+                         'runners/run.py:238)')
     ap.add_argument('--buddy-links', type=int, default=None,
                     help='pairs per BUDDY precompute (default: min(the config\'s L, 64 batches)); a step = the build + all of them')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
@@ -233,10 +236,10 @@ def main():
         return f
 
     def step_buddy(mark=False):
-        """one build, then this rank's share of the whole link set in chunks of B pairs (datasets/elph.py:200-208:
+        """one build, then this rank's share of the whole link set in chunks of --buddy-chunk pairs (datasets/elph.py:200-208:
         get_subgraph_features(links, hashes, cards, subgraph_feature_batch_size)), one gather of all feature rows"""
         table, cards = build_tables()
-        f = eh.get_subgraph_features(links, table, cards, batch_size=batch)
+        f = eh.get_subgraph_features(links, table, cards, batch_size=a.buddy_chunk)
         gather(f)
         return f
 
@@ -345,7 +348,7 @@ def main():
         'vs_baseline': None, 'dtype': 'u32/u8 sketches, f32 estimator', 'data': 'synthetic',
         'config': {'workload': f'ogbl-{a.config}-like synthetic {a.graph} graph' + (' (BASELINE configs[1])' if a.config == 'collab' else '') +
                                ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps' +
-                               ('' if a.api == 'build_query' else f' [api mode: {a.api}' + (f', {buddy_batches} batches of {batch} pairs per build' if a.api == 'buddy' else '')
+                               ('' if a.api == 'build_query' else f' [api mode: {a.api}' + (f', {pairs_planned} links per build, get_subgraph_features in chunks of {a.buddy_chunk} (datasets/elph.py:207-208)' if a.api == 'buddy' else '')
                                 + (', last-hop MinHash rows computed for the queried nodes only (hashing.DEFER_TABLE_HOP; SS_DEFER_TABLE_HOP=0: all N rows)'
                                    if a.api == 'elph' and ssa.hashing.DEFER_TABLE_HOP else '') + ']'),
                    'num_nodes': n, 'directed_edges': e_dir, 'max_hash_hops': h, 'minhash_num_perm': P, 'hll_p': HLL_P,
