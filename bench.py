@@ -62,6 +62,9 @@ def synthetic_graph(n=N_NODES, e_und=E_UND, kind='uniform', alpha=0.5, seed=1):
     rng = np.random.RandomState(seed)
     if kind == 'uniform':
         e = rng.randint(0, n, size=(2, e_und)).astype(np.int64)
+    elif kind == 'local':  # edges stay within a window of ids (ids correlated with communities / time): neighbourhoods overlap
+        s = rng.randint(0, n, size=e_und).astype(np.int64)
+        e = np.stack([s, (s + np.rint(rng.normal(0.0, alpha, size=e_und)).astype(np.int64)) % n])
     else:  # power-law endpoint weights w_i ~ (i+1)^-alpha (Chung-Lu style): exercises hub rows
         w = np.arange(1, n + 1, dtype=np.float64) ** -alpha
         cdf = np.cumsum(w / w.sum())
@@ -135,8 +138,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--config', default='collab', choices=sorted(CONFIGS), help='synthetic shape (default: BASELINE configs[1])')
-    ap.add_argument('--graph', default='uniform', choices=['uniform', 'powerlaw'])
-    ap.add_argument('--alpha', type=float, default=0.5, help='power-law exponent of the endpoint weights')
+    ap.add_argument('--graph', default='uniform', choices=['uniform', 'powerlaw', 'local'])
+    ap.add_argument('--alpha', type=float, default=0.5, help='power-law exponent of the endpoint weights; --graph local: standard deviation of dst - src')
     ap.add_argument('--batch', type=int, default=None, help='pairs per query batch (default: the config\'s)')
     ap.add_argument('--api', default='build_query', choices=['build_query', 'elph', 'buddy'],
                     help='build_query (default, the BASELINE metric): build_hash_tables + get_subgraph_features per step; '
