@@ -38,7 +38,7 @@ def timed(fn, reps=5):
 
 
 full = timed(lambda: eh.build_hash_tables(n, ei))
-print(f'N={n} E_dir={2 * cfg['e_und']} h={h}: unsharded build {full:.3f} ms', flush=True)
+print(f'N={n} E_dir={2 * cfg["e_und"]} h={h}: unsharded build {full:.3f} ms', flush=True)
 for r in (0, G // 2, G - 1):
     t = timed(lambda: eh._build(n, ei, Shard(r)))
     print(f'rank {r} of {G}: CSR (replicated) + own rows of {h} hops {t:.3f} ms', flush=True)
