@@ -355,3 +355,16 @@ def test_reference_modules_import_the_shim(ssa, monkeypatch, tmp_path):
     assert model.init_hashes is None and callable(model.elph_hashes.hll_prop) and callable(model.elph_hashes.minhash_prop)
     ref_data = importlib.import_module('src.datasets.elph')
     assert ref_data.ElphHashes is shim.ElphHashes                       # HashDataset.__init__ (datasets/elph.py:31) will build ours
+
+
+def test_every_python_file_compiles():
+    """tools/ and probes are not imported by any other test: at least their syntax is checked on this interpreter"""
+    import glob
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [f for pat in ('*.py', 'tools/*.py', 'tests/*.py', 'oracle/*.py', 'integration/src/*.py', 'subgraph-sketching_amd/*.py')
+             for f in glob.glob(os.path.join(root, pat))]
+    assert len(files) > 40
+    for f in files:
+        py_compile.compile(f, doraise=True)
