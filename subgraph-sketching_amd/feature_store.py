@@ -6,8 +6,8 @@ floats = 21 GB for ogbl-citation2) and each training / inference batch then does
     subgraph_features = data.subgraph_features[sf_indices].to(device)        # runners/train.py:58-60, inference.py:119-120
 
 i.e. a host gather + a PCIe copy per batch.  With the sketch tables resident in HBM the same rows are cheaper to RECOMPUTE per
-batch than to gather on the host and ship (tools/probe_feature_store.py, 2.66 M links: 19 / 531 / 1 045 M pairs/s at batches of
-1 024 / 65 536 / 1 M against 1.5-2.1 / 26-31 / 21-22 M pairs/s for the host-tensor hand-off: 13-47x),
+batch than to gather on the host and ship (tools/probe_feature_store.py, 2.66 M links, two boxes: 19-23 / 531-700 / 1 045-1 177 M
+pairs/s at batches of 1 024 / 65 536 / 1 M against 1.5-14 / 26-370 / 21-30 M pairs/s for the host-tensor hand-off: 1.6-47x),
 and nothing of size L x F ever exists.  `DeviceFeatureStore` is the object to put where `HashDataset.subgraph_features` is:
 it answers the indexing the reference's loops and dataset code perform on that tensor
 

@@ -20,6 +20,7 @@ import subgraph_sketching_amd as ssa
 ap = argparse.ArgumentParser()
 ap.add_argument('--json', default=None)
 ap.add_argument('--links', type=int, default=2_662_400)
+ap.add_argument('--only', default=None, help='time one variant only (host_tensor_pageable | host_tensor_pinned_source | device_feature_store)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 n = bench.N_NODES
@@ -36,9 +37,13 @@ for batch in (1024, 65536, 1048576):
     perm = torch.randperm(L, generator=torch.Generator().manual_seed(0))
     batches = [perm[s:s + batch] for s in range(0, L - batch + 1, batch)][:200]
     res = {'batch': batch, 'batches_timed': len(batches)}
-    for name, fn in (('host_tensor_pageable', lambda idx: host[idx].to(dev)),
-                     ('host_tensor_pinned_source', lambda idx: pinned[idx].to(dev, non_blocking=True)),
-                     ('device_feature_store', lambda idx: store[idx])):
+    # (the store first: after the two host-tensor loops -- hundreds of MB of freshly gathered pageable tensors -- the pageable upload
+    # of ITS index tensor has been seen 20x slower; each variant is meant to be timed on a quiet allocator)
+    for name, fn in (('device_feature_store', lambda idx: store[idx]),
+                     ('host_tensor_pageable', lambda idx: host[idx].to(dev)),
+                     ('host_tensor_pinned_source', lambda idx: pinned[idx].to(dev, non_blocking=True))):
+        if a.only and name != a.only:
+            continue
         fn(batches[0]); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for idx in batches:
