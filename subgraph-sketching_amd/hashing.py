@@ -11,6 +11,7 @@ tensors), HyperLogLog uint8[N, M].  `build_hash_tables` returns a `SketchTable`,
 {hop: {'hll': int8[N, M], 'minhash': int64[N, P]}} exactly like the reference's, whose int64 MinHash
 leaves are only materialised if somebody reads them (torch.save does); the kernels use the packed twin.
 """
+import atexit
 import logging
 import os
 import weakref
@@ -97,6 +98,20 @@ def _take_error(device):
     return bad
 
 
+_LIVE_DEFERRED = weakref.WeakSet()
+
+
+@atexit.register
+def _warn_unreported_bounds_errors():  # pragma: no cover (interpreter exit)
+    try:
+        if any(d.unreported() for d in list(_LIVE_DEFERRED)):
+            logger.warning('subgraph_sketching_amd: a launch met node ids outside its num_nodes and no later call reported it '
+                           '(strict_bounds="deferred"): out-of-range edges were dropped / pairs returned NaN rows. '
+                           'Call ElphHashes.check_errors() after the last call, or set strict_bounds = True.')
+    except Exception:
+        pass
+
+
 class _DeferredErrors(object):
     """strict_bounds = 'deferred': kernels report out-of-range node ids into a PINNED HOST int32 (hipHostMalloc memory is
     mapped into the device's address space at the same address; the store only happens on an error), which the host reads
@@ -106,6 +121,11 @@ class _DeferredErrors(object):
 
     def __init__(self):
         self._flags, self._calls = {}, []
+        _LIVE_DEFERRED.add(self)
+
+    def unreported(self):
+        """non-waiting look at the report words (for the exit hook: a program whose LAST call had bad ids never comes back to raise)"""
+        return any(int(f[0]) for f in self._flags.values())
 
     def flag(self, device, what):
         key = str(device)
