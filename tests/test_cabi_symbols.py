@@ -70,6 +70,23 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ss_pack_minhash(None, None, -1, None) == -1
     assert lib.ss_fused_hop_stage(None, None, None, 128, None, None, 8, None, None, None, None, 0, None, None) == -1   # no graph
     assert lib.ss_pair_features(None, 0, 0, 4, None, 128, None, None, 0, None, 0, None, None, None, None, None, None) == -4  # h = 4
+    assert lib.ss_minhash_hop_rows(None, None, None, 128, None, 0, None) == -1                                                 # no graph
+    assert lib.ss_first_hop(None, None, None, 128, None, 8, None, None, 0, None, None) == -1
+    assert lib.ss_propagate(None, None, None, 128, None, None, 256, None, 0, None, None) == -1
+    g = ssa._native.CsrGraphStruct(rowptr=8, col=8, num_nodes=4, n_self_loops=0, n_self_loops_dev=None, hub_threshold=512, reserved=0,
+                                   hub_rows=None, hub_count=None, mega_rows=None, mega_count=None, mega_scratch=None, row_begin=0, row_end=0)
+    from ctypes import byref, c_void_p
+    fake = c_void_p(8)   # never dereferenced: every call below is rejected by the host-side checks
+    assert lib.ss_minhash_hop_rows(byref(g), fake, fake, 130, fake, 4, None) == -1      # P not a multiple of 4
+    assert lib.ss_minhash_hop_rows(byref(g), fake, fake, 128, None, 4, None) == -1      # rows missing
+    assert lib.ss_minhash_hop_rows(byref(g), fake, fake, 128, fake, -1, None) == -1
+    assert lib.ss_minhash_hop_rows(byref(g), fake, fake, 128, None, 0, None) == 0       # empty list: nothing to do
+    g.row_begin, g.row_end = 1, 3
+    assert lib.ss_minhash_hop_rows(byref(g), fake, fake, 128, fake, 4, None) == -1      # a row list and a row range exclude each other
+    assert lib.ss_first_hop(byref(g), fake, fake, 100, fake, 8, None, None, 0, None, None) == -4     # no first-hop kernel for P = 100
+    assert lib.ss_first_hop(byref(g), fake, fake, 128, None, 6, fake, None, 0, None, None) == -4     # HLL first hop is p = 8 only
+    g.row_begin, g.row_end = 3, 1
+    assert lib.ss_propagate(byref(g), fake, fake, 128, None, None, 256, None, 0, None, None) == -1   # empty / reversed row range
 
 
 def test_missing_library_fails_loudly(monkeypatch):
