@@ -1,0 +1,75 @@
+"""fuzz: random graph shapes, hop counts, hub thresholds and batch sizes through BOTH call styles -- build_hash_tables +
+get_subgraph_features (BUDDY) and the ELPH call sequence with its deferred launches (fused stage, row-list table hop) --
+against the C oracle: tables bit-exact, features within the stated tolerance, the two call styles bit-identical to each other.
+usage (GPU box): python tests/fuzz_parity.py [seconds = 120]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+import subgraph_sketching_amd as ssa
+from oracle import oracle
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+dev = torch.device('cuda:0')
+H = ssa.hashing
+t8 = ssa.hll_tables.load(8, prefer='regenerated')
+prm = oracle.HllParams(t8.p, t8.threshold, t8.raw_estimate, t8.bias, alpha=t8.alpha, lc_table=H.linear_counting_table(256).numpy())
+rng = np.random.RandomState(int(os.environ.get('FUZZ_SEED', '12345')))
+t0, trials, bad = time.time(), 0, 0
+while time.time() - t0 < seconds:
+    n = int(rng.choice([60, 900, 7000, 40000]))
+    e_und = int(n * rng.choice([0.5, 3, 10, 40]))
+    h = int(rng.choice([1, 2, 3]))
+    if rng.randint(3) == 0:  # skewed endpoints: hub rows, with a low threshold also mega-ish rows
+        w = np.arange(1, n + 1, dtype=np.float64) ** -float(rng.choice([0.5, 0.9, 1.2]))
+        cdf = np.cumsum(w / w.sum())
+        e = np.stack([np.minimum(np.searchsorted(cdf, rng.random_sample(e_und)), n - 1), rng.randint(0, n, size=e_und)])
+    else:
+        e = rng.randint(0, n, size=(2, e_und))
+    if rng.randint(4) == 0:
+        e = e[:, e.max(axis=0) < n - 5] if e.shape[1] else e  # trailing nodes without a self loop
+    ei = np.concatenate([e, e[::-1]], axis=1).astype(np.int64)
+    H.HUB_THRESHOLD = int(rng.choice([0, 0, 8, 40, 300])) or None
+    B = int(rng.choice([1, 17, 400, 5000]))
+    links = rng.randint(-n, n, size=(B, 2)).astype(np.int64)
+    eh = ssa.ElphHashes(Namespace(max_hash_hops=h, hll_p=8, minhash_num_perm=128, floor_sf=bool(rng.randint(2)), use_zero_one=bool(rng.randint(2))))
+    eh.hll_tables = t8
+    tag = f'n={n} e_dir={ei.shape[1]} h={h} B={B} hub={H.HUB_THRESHOLD}'
+    otab, ocards = oracle.build_hash_tables(n, ei, h, 128, prm)
+    lk_pos = np.where(links < 0, links + n, links)
+    ofeat = oracle.pair_features(lk_pos, otab, ocards, h, prm, use_zero_one=eh.use_zero_one, floor_sf=eh.floor_sf)
+    ok = True
+    # BUDDY style
+    tei, tlk = torch.from_numpy(ei).to(dev), torch.from_numpy(links).to(dev)
+    table, cards = eh.build_hash_tables(n, tei)
+    for k in range(1, h + 1):
+        ok &= np.array_equal(table[k].mh_u32.cpu().numpy().view(np.uint32), otab[k]['minhash'])
+        ok &= np.array_equal(table[k].hll_u8.cpu().numpy(), otab[k]['hll'])
+    f1 = eh.get_subgraph_features(tlk, table, cards)
+    scale = max(1.0, float(np.abs(ofeat).max()) / 100) if ofeat.size else 1.0
+    ok &= bool(np.allclose(f1.cpu().numpy(), ofeat, rtol=1e-4, atol=1e-4 * scale))
+    # ELPH style (explicit self loops over max(edge_index) + 1 nodes, per-hop modules, deferred launches)
+    if ei.shape[1]:
+        n_loops = int(ei.max()) + 1
+        hei = torch.cat([tei, torch.arange(n_loops, device=dev).repeat(2, 1)], dim=1)
+        tb = {0: {'minhash': eh.initialise_minhash(n), 'hll': eh.initialise_hll(n)}}
+        cd = torch.zeros((n, h), device=dev)
+        for k in range(1, h + 1):
+            tb[k] = {'hll': eh.hll_prop(tb[k - 1]['hll'], hei), 'minhash': eh.minhash_prop(tb[k - 1]['minhash'], hei)}
+            cd[:, k - 1] = eh.hll_count(tb[k]['hll'])
+        f2 = eh.get_subgraph_features(tlk, tb, cd, batch_size=int(rng.choice([11000000, 7, 333])))
+        ok &= torch.equal(f2, f1)
+        for k in range(1, h + 1):  # whoever asks afterwards gets the whole tables
+            ok &= np.array_equal(H._packed_minhash_of(tb[k]['minhash'], dev).cpu().numpy().view(np.uint32), otab[k]['minhash'])
+    eh.check_errors()
+    trials += 1
+    if not ok:
+        bad += 1
+        print('MISMATCH', tag, flush=True)
+print(f'{trials} trials, {bad} mismatches, {time.time() - t0:.0f} s')
+sys.exit(1 if bad else 0)
