@@ -174,8 +174,13 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
 #pragma unroll
         for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4 *>(row + 64 * k + 4 * l) = u32x4{0u, 0u, 0u, 0u};
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // (the id of the lane's NEXT neighbour is requested before the current one is hashed -- unconditionally, from an address
+        // that always exists: rows of more than 16 neighbours otherwise pay one exposed round trip per 16 neighbours)
+        int cur = nid0[r];
         for (int t = l; t < total; t += kRow) {
-            const int64_t nid = t < deg ? (t < kRow ? (int64_t)nid0[r] : (int64_t)nb[t]) : i;
+            const int nxt = *(t + kRow < deg ? nb + t + kRow : always_valid);
+            const int64_t nid = t < deg ? (int64_t)cur : i;
+            cur = nxt;
             const uint64_t hv = hash_u64((uint64_t)(nid + 1));
             const uint64_t bits = hv >> p;
             const int bl = bits ? 64 - __builtin_clzll(bits) : 0;
