@@ -21,6 +21,7 @@ ap.add_argument('--json', default=None)
 ap.add_argument('--nodes', type=int, default=235868)
 ap.add_argument('--hops', type=int, nargs='*', default=[2, 3])
 ap.add_argument('--batches', type=int, nargs='*', default=[1024, 2048, 8192, 65536, 262144, 1048576, 4194304])
+ap.add_argument('--sorted', action='store_true', help='links ordered by source node (a coalesced edge list: consecutive pairs share u)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 n = a.nodes
@@ -36,6 +37,8 @@ for h in a.hops:
     mh_ptrs = (c_void_p * h)(*[t.data_ptr() for t in mh]); hl_ptrs = (c_void_p * h)(*[t.data_ptr() for t in hl])
     for B in a.batches:
         links = torch.randint(0, n, (B, 2), device=dev)
+        if a.sorted:
+            links = links[torch.argsort(links[:, 0])].contiguous()
         out = torch.empty((B, h * (h + 2)), device=dev)
         ms = c_float()
         rc = lib.ss_time_pair_features(_ptr(links), B, n, h, mh_ptrs, 128, hl_ptrs, _ptr(cards), h, byref(prm.struct), 1, _ptr(out), _stream(dev), 20, byref(ms))
