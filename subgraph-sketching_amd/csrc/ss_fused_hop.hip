@@ -20,9 +20,9 @@
 // Mapping: a wavefront owns kFusedRows = 4 consecutive destination rows.  MinHash side: as first_hop_rows_kernel (with 4 rows the
 // 60 col entries of a batch almost always cover the whole chunk: a batch reload in the middle of the walk would have to wait for
 // its ids with vmcnt(0) -- vmcnt retires in order -- and so for every HLL row posted before it).  HLL side: one 16-lane DPP row
-// per destination (lane c = 16-byte chunk c of the 256-byte row); the first kHllInFlight = 12 neighbour chunks per lane are
-// requested up front (ids by one coalesced load per lane group, handed out by DPP row_newbcast), the rest of longer rows after
-// the MinHash walk (hll_row16_finish).  Hub rows are skipped by both sides and
+// per destination (lane c = 16-byte chunk c of the 256-byte row); the first kHllInFlight = 11 neighbour chunks per lane are
+// requested into registers up front and the next kHllLds = 5 into LDS (global_load_lds_dwordx4; ids by one coalesced load per
+// lane group, handed out by DPP row_newbcast), the rest of rows longer than 16 after the MinHash walk (hll_row16_finish).  Hub rows are skipped by both sides and
 // served by the two hub kernels afterwards.  P = 64 * PPL, M = 256 (p = 8) only -- the shapes ss_first_hop has a kernel for.
 #include <cstdlib>
 
@@ -92,9 +92,10 @@ __device__ __forceinline__ void hll_fold(const HllPosted &h, u32x4 &ae, u32x4 &a
 //     ids(k) arrive  ->  post HLL rows(k)  ->  post ids(k+1) [bounds(k+1) arrived an iteration ago]  ->  post bounds(k+2)
 //     ->  MinHash walk(k)  [VALU; everything above travels]  ->  fold HLL rows(k), finish, store
 // vmcnt retires in order and that is exactly the order of use, so no wait ever covers a younger load.
-// Measured (bench graph): two separate launches 82 + 102 = 184 us; one chunk per wavefront 174 us; this kernel 166-170 us (step
-// 0.494 -> 0.478 ms).  The VALU work alone would be ~120 us: what is left are the loads of rows with more than 12 neighbours, issued
-// and awaited after the walk.  A rolling window (fold four posted chunks after every MinHash row and re-post their registers with the
+// Measured (bench graph): two separate launches 82 + 102 = 184 us; one chunk per wavefront 174 us; this kernel 166-170 us with 12
+// chunks in registers and nothing in LDS (step 0.494 -> 0.478 ms), 151 us as it stands.  The VALU work alone would be
+// ~100-120 us: what is left are the loads of rows with more than 16 neighbours, issued and awaited after the walk.  Register-only
+// attempts at more coverage: a rolling window (fold four posted chunks after every MinHash row and re-post their registers with the
 // row's next four neighbours) covered 24 neighbours but cost 157-167 VGPRs (three wavefronts per SIMD): 181-196 us; a single re-post of
 // 8 chunks before the last MinHash row (coverage 16, 134 VGPRs): 184 us.  Not shipped: the kernel lives on its fourth wavefront.
 template <int PPL>
