@@ -105,7 +105,7 @@ typedef struct ss_csr_graph {
  *   err_flag: device int32 (nullable), set to 1 if any endpoint is outside [0, N) (such edges are dropped).
  * Workspace: ss_csr_workspace_bytes(N, E) bytes (0 = unsupported size).  No per-edge global atomics: a
  * two-level counting sort (LDS histograms per edge slice -> bucket offsets -> per-bucket LDS sort). */
-#define SS_MEGA_SLICE 4096      /* neighbours per slice of a mega row */
+#define SS_MEGA_SLICE 1024      /* neighbours per slice of a mega row (one 64-neighbour chunk per wavefront of a hub workgroup) */
 #define SS_MEGA_SLOT_BYTES 1280 /* scratch per slice: partial MinHash row (<= 256 x u32) + partial HLL row (256 B) */
 size_t ss_csr_workspace_bytes(int64_t N, int64_t E);
 /* mega_rows / mega_count (nullable together): rows with more than max(hub_threshold, SS_MEGA_SLICE) in-edges are listed

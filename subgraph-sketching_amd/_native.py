@@ -31,9 +31,9 @@ class CsrGraphStruct(ctypes.Structure):
                 ('mega_scratch', c_void_p), ('row_begin', c_int64), ('row_end', c_int64)]
 
 
-ABI_VERSION = 123  # ss_version() of the library this module's struct mirrors and signatures describe
+ABI_VERSION = 124  # ss_version() of the library this module's struct mirrors and signatures describe
 PROF_MINHASH_HOP, PROF_HLL_HOP, PROF_FIRST_HOP_MH, PROF_FIRST_HOP_HLL, PROF_PAIRS, PROF_CSR, PROF_HUB, PROF_FUSED, PROF_MINHASH_ROWS = range(9)  # SS_PROF_* tags
-MEGA_SLICE, MEGA_SLOT_BYTES = 4096, 1280  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
+MEGA_SLICE, MEGA_SLOT_BYTES = 1024, 1280  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/subgraph_sketch.h and include/subgraph_sketch_debug.h

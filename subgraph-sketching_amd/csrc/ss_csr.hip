@@ -22,6 +22,7 @@
 // The pass-1 scatter also validates ids and reduces max(id)+1 (the self-loop count of add_self_loops,
 // hashing.py:148); the finish step lists hub rows.  Nothing synchronises with the host.
 #include <cstdlib>
+#include <cstring>
 
 #include "ss_common.hpp"
 
@@ -34,6 +35,19 @@ constexpr int kMaxBlocks1 = 2048;      // pass-1 slices
 constexpr int kFinishThreads = 1024;      // (512: bench graph 46-48 us, rank^-0.5 133-137, rank^-0.9 640; 1024: 45, 121, 567)
 constexpr int kFinishCap = 16384;      // edges staged in LDS by the finish step (64 KiB)
 constexpr int kMaxTiles = 1536;        // single-pass plan: tiles whose run descriptors fit the finish step's LDS beside the image (2 workgroups per CU)
+// Dense fine buckets (node ids correlated with degree: power-law graphs put 5 - 40 % of the edges into the first 1024 nodes) are
+// NOT finished by their one workgroup -- a single CU reading the segment twice was the whole build on such graphs (532 us of a
+// 1.23 ms step at rank^-0.9 endpoints, 97 us at rank^-0.5 against 21 us uniform).  The finish launch only registers them; two
+// further launches split each by EDGES over several workgroups: dense_count (LDS histogram of a share, ONE global atomic per
+// touched node and share: its return value is the share's offset inside the node's row) and dense_place (row starts from the
+// summed counters, sources stored at start + share offset + LDS cursor).  Both exit at once when nothing was registered.
+constexpr int kDenseMin = 32768;       // a fine bucket with more edges than this is split ...
+constexpr int kDensePart = 16384;      // ... into shares of about this many edges
+constexpr int kDenseGrid = 1024;       // workgroups of the two dense launches (each loops over the shares)
+// dense_count words: [0] dense buckets, [1] shares, [3] helpers done counting, [kArriveBase + 16 k] (k < kArriveWords, one cache
+// line each) fine buckets whose workgroup has decided -- 64 sharded words: a large graph has tens of thousands of fine buckets
+// and one word takes ~90 atomics per microsecond
+constexpr int kArriveBase = 16, kArriveWords = 64, kDenseSyncInts = kArriveBase + 16 * kArriveWords;
 
 struct CsrPlan {
     int node_shift;       // fine bucket = dst >> node_shift
@@ -111,6 +125,12 @@ inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+struct DenseBucket {  // a fine bucket left to the dense launches
+    int32_t bucket, first_share, shares;
+    uint32_t n;                 // edges
+    unsigned long long base;    // start of the bucket in col
+};
+
 struct Workspace {
     uint32_t *counts1;              // [keys1][blocks1]
     unsigned long long *base1;      // [keys1 + 1]
@@ -122,8 +142,15 @@ struct Workspace {
     int2 *staged_a, *staged_b;      // [E] each
     uint32_t *tile_off;             // gather plan: [keys1 + 1][tiles]
     unsigned long long *tile_max;   // gather plan: [tiles]
+    int32_t *dense_count;           // [2] {dense buckets, shares}
+    DenseBucket *dense_list;        // [max_dense]
+    uint32_t *dense_node_cnt;       // [max_dense][1024] edges per node of a dense bucket
+    uint32_t *dense_share_off;      // [max_shares][1024] offset of a share's edges inside each node's row
     size_t bytes;
 };
+
+inline int64_t max_dense_buckets(int64_t E) { return E / kDenseMin + 1; }
+inline int64_t max_dense_shares(int64_t E) { return E / kDensePart + max_dense_buckets(E) + 1; }
 
 inline Workspace carve(const CsrPlan &p, int64_t E, void *base)
 {
@@ -142,6 +169,10 @@ inline Workspace carve(const CsrPlan &p, int64_t E, void *base)
     w.staged_b = reinterpret_cast<int2 *>(take(p.two_pass ? (size_t)(E > 0 ? E : 1) * 8 : 0));
     w.tile_off = reinterpret_cast<uint32_t *>(take(p.gather ? (size_t)(p.keys1 + 1) * p.tiles * 4 : 0));
     w.tile_max = reinterpret_cast<unsigned long long *>(take(p.gather ? (size_t)p.tiles * 8 : 0));
+    w.dense_count = reinterpret_cast<int32_t *>(take(4 * kDenseSyncInts));
+    w.dense_list = reinterpret_cast<DenseBucket *>(take((size_t)max_dense_buckets(E) * sizeof(DenseBucket)));
+    w.dense_node_cnt = reinterpret_cast<uint32_t *>(take((size_t)max_dense_buckets(E) * 1024 * 4));
+    w.dense_share_off = reinterpret_cast<uint32_t *>(take((size_t)max_dense_shares(E) * 1024 * 4));
     w.bytes = off;
     return w;
 }
@@ -234,14 +265,16 @@ __device__ __forceinline__ int key_of(const PassArgs &a, int64_t d, int group)
 template <bool PASS2>
 __global__ __launch_bounds__(kThreads) void count_keys_kernel(PassArgs a, uint32_t *__restrict__ counts, int32_t *__restrict__ err,
                                                               unsigned long long *__restrict__ n_self, int32_t *__restrict__ hub_count,
-                                                              int32_t *__restrict__ mega_count)
+                                                              int32_t *__restrict__ mega_count, int32_t *__restrict__ dense_count)
 {
     __shared__ uint32_t hist[kMaxKeys];
     if (!PASS2 && blockIdx.x == 0 && threadIdx.x == 0) {  // outputs of later kernels of this build are cleared here
         *n_self = 0ULL;
         if (hub_count) *hub_count = 0;
         if (mega_count) mega_count[0] = mega_count[1] = 0;
+        dense_count[0] = dense_count[1] = dense_count[2] = dense_count[3] = 0;
     }
+    if (!PASS2 && blockIdx.x == 0 && threadIdx.x < kArriveWords) dense_count[kArriveBase + 16 * threadIdx.x] = 0;
     hist[threadIdx.x] = 0;
     __syncthreads();
     int64_t lo, hi;
@@ -512,64 +545,108 @@ struct FinishLds {
     uint32_t wave_tot[kFinishThreads / kWave];
 };
 
+// what the finish step writes besides col: rowptr and the hub / mega row lists
+struct RowOutputs {
+    int64_t *rowptr;
+    int hub_threshold;
+    int32_t *hub_rows, *hub_count, *mega_rows, *mega_count;
+};
+
+// exclusive scan of the per-node edge counts cnt[0..nb) of the bucket that starts at node0 -> excl[0..nb]; with `publish` the
+// row starts (rowptr) and the hub / mega rows of the bucket are written too.  Called by all kFinishThreads threads.
+__device__ __forceinline__ void scan_bucket_nodes(const uint32_t *cnt, uint32_t *excl, uint32_t *wave_tot, int nb, int64_t node0, int64_t N,
+                                                  unsigned long long seg_lo, uint32_t seg_n, bool publish, const RowOutputs &o)
+{
+    // two counters per thread at nb = 1024
+    const int per = (nb + kFinishThreads - 1) / kFinishThreads;
+    const int b0 = threadIdx.x * per;
+    uint32_t run = 0;
+    for (int k = 0; k < per; ++k) run += (b0 + k < nb) ? cnt[b0 + k] : 0u;
+    uint32_t inc = run;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t x = __shfl_up(inc, off);
+        if (lane >= off) inc += x;
+    }
+    if (lane == kWave - 1) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int w = 0; w < wv; ++w) pre += wave_tot[w];
+    uint32_t ex = pre + inc - run;
+    for (int k = 0; k < per; ++k) {
+        if (b0 + k >= nb) break;
+        const uint32_t c = cnt[b0 + k];
+        excl[b0 + k] = ex;
+        if (publish && node0 + b0 + k < N) {
+            o.rowptr[node0 + b0 + k] = (int64_t)(seg_lo + ex);
+            // (cross-workgroup appends: agent-scope atomics on the counters, plain stores into the claimed slots; nothing in
+            // THIS launch reads the lists -- the propagation launches do, and a kernel boundary orders them behind these stores)
+            if (o.hub_rows && c > (uint32_t)o.hub_threshold) {
+                if (o.mega_rows && c > (uint32_t)SS_MEGA_SLICE) {  // walked slice by slice by all hub workgroups
+                    const int slices = (int)((c + 1 + SS_MEGA_SLICE - 1) / SS_MEGA_SLICE);  // + 1: the implicit self loop
+                    const int m = atomicAdd(&o.mega_count[0], 1);
+                    const int first = atomicAdd(&o.mega_count[1], slices);
+                    reinterpret_cast<int4 *>(o.mega_rows)[m] = make_int4((int)(node0 + b0 + k), first, slices, 0);
+                } else {
+                    o.hub_rows[atomicAdd(o.hub_count, 1)] = (int32_t)(node0 + b0 + k);
+                }
+            }
+        }
+        ex += c;
+    }
+    if (threadIdx.x == 0) excl[nb] = seg_n;
+}
+
+// where the finish step registers the buckets it leaves to the dense launches
+struct DenseArgs {
+    int32_t *count;         // [kDenseSyncInts], see above
+    DenseBucket *list;
+    uint32_t *node_cnt;     // [dense bucket][1024]
+    uint32_t *share_off;    // [share][1024]
+    int helpers;            // helper workgroups appended to the finish launch (0: the dense steps are launches of their own)
+};
+
 template <typename Edges>
 __device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int node_shift,
-                                              int64_t N, int64_t *__restrict__ rowptr, int32_t *__restrict__ col, int hub_threshold,
-                                              int32_t *__restrict__ hub_rows, int32_t *__restrict__ hub_count,
-                                              int32_t *__restrict__ mega_rows, int32_t *__restrict__ mega_count)
+                                              int64_t N, int32_t *__restrict__ col, const RowOutputs &o, const DenseArgs &dense)
 {
     uint32_t *cnt = lds.cnt, *excl = lds.excl;
     const int nb = 1 << node_shift;  // <= 1024 nodes
     const int64_t node0 = (int64_t)blockIdx.x << node_shift;
+    if (seg_n > (uint32_t)kDenseMin) {  // (workgroup-uniform) split by edges over several workgroups: dense_count / dense_place
+        if (threadIdx.x == 0) {
+            const int shares = (int)((seg_n + kDensePart - 1) / kDensePart);
+            const int d = atomicAdd(&dense.count[0], 1);
+            const int first = atomicAdd(&dense.count[1], shares);
+            dense.list[d] = DenseBucket{(int32_t)blockIdx.x, first, shares, seg_n, seg_lo};
+            lds.wave_tot[0] = (uint32_t)d;
+        }
+        __syncthreads();
+        uint32_t *mine = dense.node_cnt + (size_t)lds.wave_tot[0] * 1024;
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads) mine[i] = 0;
+        if (dense.helpers) {  // the helpers of THIS launch read the descriptor and add to the counters: publish (G16 producer form)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&dense.count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    if (dense.helpers && threadIdx.x == 0)
+        __hip_atomic_fetch_add(&dense.count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = threadIdx.x; i < nb; i += kFinishThreads) cnt[i] = 0;
     __syncthreads();
     edges.for_each([&](int2 v) { atomicAdd(&cnt[v.y - (int)node0], 1u); });
     __syncthreads();
-    {   // exclusive scan of cnt[0..nb): two counters per thread at nb = 1024
-        const int per = (nb + kFinishThreads - 1) / kFinishThreads;
-        const int b0 = threadIdx.x * per;
-        uint32_t run = 0;
-        for (int k = 0; k < per; ++k) run += (b0 + k < nb) ? cnt[b0 + k] : 0u;
-        uint32_t inc = run;
-        const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
-        }
-        if (lane == kWave - 1) lds.wave_tot[wv] = inc;
-        __syncthreads();
-        uint32_t pre = 0;
-        for (int w = 0; w < wv; ++w) pre += lds.wave_tot[w];
-        uint32_t ex = pre + inc - run;
-        for (int k = 0; k < per; ++k) {
-            if (b0 + k >= nb) break;
-            const uint32_t c = cnt[b0 + k];
-            excl[b0 + k] = ex;
-            if (node0 + b0 + k < N) {
-                rowptr[node0 + b0 + k] = (int64_t)(seg_lo + ex);
-                // (cross-workgroup appends: agent-scope atomics on the counters, plain stores into the claimed slots; nothing in
-                // THIS launch reads the lists -- the propagation launches do, and a kernel boundary orders them behind these stores)
-                if (hub_rows && c > (uint32_t)hub_threshold) {
-                    if (mega_rows && c > (uint32_t)SS_MEGA_SLICE) {  // walked slice by slice by all hub workgroups
-                        const int slices = (int)((c + 1 + SS_MEGA_SLICE - 1) / SS_MEGA_SLICE);  // + 1: the implicit self loop
-                        const int m = atomicAdd(&mega_count[0], 1);
-                        const int first = atomicAdd(&mega_count[1], slices);
-                        reinterpret_cast<int4 *>(mega_rows)[m] = make_int4((int)(node0 + b0 + k), first, slices, 0);
-                    } else {
-                        hub_rows[atomicAdd(hub_count, 1)] = (int32_t)(node0 + b0 + k);
-                    }
-                }
-            }
-            ex += c;
-        }
-        if (threadIdx.x == 0) excl[nb] = seg_n;
-    }
+    scan_bucket_nodes(cnt, excl, lds.wave_tot, nb, node0, N, seg_lo, seg_n, true, o);
     __syncthreads();
     // place the sources: node sub-ranges [n_lo, n_hi) whose edges fit the LDS image (one range when seg_n <= cap).
     // Every sub-range re-reads the whole segment, so a bucket far above the cap (hub-heavy buckets of power-law graphs)
     // is placed in ONE sweep straight into global memory instead: scattered 4-byte stores, but only for those buckets.
-    const bool all_direct = seg_n > 4u * (uint32_t)kFinishCap;
+    const bool all_direct = seg_n > 4u * (uint32_t)kFinishCap;  // (only reachable if kDenseMin is raised above 4 caps)
     int n_lo = 0;
     while (n_lo < nb) {
         // largest n_hi with excl[n_hi] - excl[n_lo] <= cap; at least one node (a single node above the cap is streamed
@@ -601,19 +678,6 @@ __device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds
     }
 }
 
-__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__restrict__ staged, const unsigned long long *__restrict__ fine_base,
-                                                                int node_shift, int64_t N, int64_t *__restrict__ rowptr,
-                                                                int32_t *__restrict__ col, int hub_threshold, int32_t *__restrict__ hub_rows,
-                                                                int32_t *__restrict__ hub_count, int32_t *__restrict__ mega_rows,
-                                                                int32_t *__restrict__ mega_count)
-{
-    __shared__ FinishLds lds;
-    const unsigned long long seg_lo = fine_base[blockIdx.x], seg_hi = fine_base[blockIdx.x + 1];
-    const uint32_t seg_n = (uint32_t)(seg_hi - seg_lo);
-    finish_bucket(ContiguousEdges{staged, seg_lo, seg_n}, lds, seg_lo, seg_n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
-                  mega_rows, mega_count);
-}
-
 // ---- single-pass plan (<= 256 fine buckets, <= kMaxTiles tiles: every shape up to ogbl-collab size) in TWO launches --------
 // tile_sort_kernel: every 4096-edge tile is sorted by bucket in LDS and written back as ONE contiguous tile (no global
 // offsets are needed for that), together with the tile's exclusive bucket offsets off[b][t] (bucket-major, so that a
@@ -630,7 +694,7 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
                                                                  int64_t N, int shift, int keys, int tiles, int2 *__restrict__ staged,
                                                                  uint32_t *__restrict__ tile_off, unsigned long long *__restrict__ tile_max,
                                                                  int32_t *__restrict__ err, int32_t *__restrict__ hub_count,
-                                                                 int32_t *__restrict__ mega_count)
+                                                                 int32_t *__restrict__ mega_count, int32_t *__restrict__ dense_count)
 {
     __shared__ int2 sorted[kTile];
     __shared__ uint32_t tile_hist[kMaxKeys], tile_offs[kMaxKeys], wave_tot[kSortThreads / kWave];
@@ -638,7 +702,9 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // outputs of the finish launch of this build are cleared here
         if (hub_count) *hub_count = 0;
         if (mega_count) mega_count[0] = mega_count[1] = 0;
+        dense_count[0] = dense_count[1] = dense_count[2] = dense_count[3] = 0;
     }
+    if (blockIdx.x == 0 && threadIdx.x < kArriveWords) dense_count[kArriveBase + 16 * threadIdx.x] = 0;
     if (threadIdx.x < kMaxKeys) tile_hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) block_max = 0;
     __syncthreads();
@@ -693,13 +759,257 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
     if (threadIdx.x == 0) tile_max[blockIdx.x] = block_max;
 }
 
+// ---- dense fine buckets: split by edges over several workgroups (two launches behind the finish launch) -----------------------
+struct DenseLds {
+    uint32_t cnt[1024], excl[1024 + 1];
+    uint32_t run_start[kMaxTiles + 1];  // gather plan: exclusive prefix of the bucket's run lengths over the tiles
+    uint32_t run_addr[kMaxTiles];       // gather plan: where each run starts in the tile-sorted array
+    uint32_t wave_tot[kFinishThreads / kWave];
+    int desc;
+};
+
+struct DenseShare {
+    DenseBucket b;
+    int index;         // share of its bucket
+    uint32_t lo, hi;   // flat edge range [lo, hi) of the bucket
+    int t_lo, t_hi;    // gather plan: tiles that hold it
+};
+
+// the bucket and the flat edge range of share `item` (all threads; contains barriers).  GATHER: also the run table of the bucket.
+template <bool GATHER>
+__device__ __forceinline__ DenseShare locate_share(DenseLds &lds, int item, int n_dense, const DenseBucket *__restrict__ list,
+                                                   const uint32_t *__restrict__ tile_off, int tiles)
+{
+    __syncthreads();  // the previous share's readers of lds are done
+    for (int i = threadIdx.x; i < n_dense; i += kFinishThreads) {
+        const int first = list[i].first_share;
+        if (item >= first && item < first + list[i].shares) lds.desc = i;
+    }
+    __syncthreads();
+    DenseShare sh;
+    sh.b = list[lds.desc];
+    sh.index = item - sh.b.first_share;
+    sh.lo = (uint32_t)((unsigned long long)sh.b.n * (unsigned)sh.index / (unsigned)sh.b.shares);
+    sh.hi = (uint32_t)((unsigned long long)sh.b.n * (unsigned)(sh.index + 1) / (unsigned)sh.b.shares);
+    sh.t_lo = 0;
+    sh.t_hi = 0;
+    if (GATHER) {
+        const uint32_t *row0 = tile_off + (int64_t)sh.b.bucket * tiles, *row1 = row0 + tiles;
+        // run lengths -> exclusive prefix (two tiles per thread; tiles <= kMaxTiles <= 2 * kFinishThreads)
+        const int t0 = 2 * threadIdx.x;
+        uint32_t len[2] = {0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (t0 + k < tiles) {
+                const uint32_t o0 = row0[t0 + k];
+                len[k] = row1[t0 + k] - o0;
+                lds.run_addr[t0 + k] = (uint32_t)(t0 + k) * (uint32_t)kTile + o0;
+            }
+        const uint32_t run = len[0] + len[1];
+        uint32_t inc = run;
+        const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t x = __shfl_up(inc, off);
+            if (lane >= off) inc += x;
+        }
+        if (lane == kWave - 1) lds.wave_tot[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (int w = 0; w < wv; ++w) pre += lds.wave_tot[w];
+        const uint32_t ex = pre + inc - run;
+        if (t0 < tiles) lds.run_start[t0] = ex;
+        if (t0 + 1 < tiles) lds.run_start[t0 + 1] = ex + len[0];
+        if (threadIdx.x == 0) lds.run_start[tiles] = sh.b.n;
+        __syncthreads();
+        // tiles holding [lo, hi): last tile whose start is <= lo .. last tile whose start is < hi
+        int a = 0, b = tiles;
+        while (b - a > 1) {
+            const int mid = (a + b) >> 1;
+            if (lds.run_start[mid] <= sh.lo) a = mid; else b = mid;
+        }
+        sh.t_lo = a;
+        b = tiles;
+        while (b - a > 1) {
+            const int mid = (a + b) >> 1;
+            if (lds.run_start[mid] < sh.hi) a = mid; else b = mid;
+        }
+        sh.t_hi = a;
+    }
+    return sh;
+}
+
+// f(edge) for every edge of the share, four loads in flight per thread
+template <bool GATHER, typename F>
+__device__ __forceinline__ void for_share(const DenseLds &lds, const DenseShare &sh, const int2 *__restrict__ staged, F &&f)
+{
+    for (uint32_t q0 = sh.lo; q0 < sh.hi; q0 += 4 * kFinishThreads) {
+        int2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t q = q0 + threadIdx.x + k * kFinishThreads;
+            v[k] = make_int2(0, -1);
+            if (q < sh.hi) {
+                if (GATHER) {
+                    int a = sh.t_lo, b = sh.t_hi + 1;  // the tile whose run holds flat edge q
+                    while (b - a > 1) {
+                        const int mid = (a + b) >> 1;
+                        if (lds.run_start[mid] <= q) a = mid; else b = mid;
+                    }
+                    v[k] = staged[lds.run_addr[a] + (q - lds.run_start[a])];
+                } else {
+                    v[k] = staged[sh.b.base + q];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (v[k].y >= 0) f(v[k]);
+    }
+}
+
+// dense_count: per-node edge counts of every share; ONE global atomic per (share, touched node), whose return value is where the
+// share's edges of that node start inside the node's row.  Shares first, first + stride, ... (all threads).
+template <bool GATHER>
+__device__ __forceinline__ void dense_count_shares(DenseLds &lds, int first, int stride, const int2 *__restrict__ staged,
+                                                   const uint32_t *__restrict__ tile_off, int tiles, int node_shift, int n_dense, int n_shares,
+                                                   const DenseBucket *__restrict__ list, uint32_t *__restrict__ node_cnt,
+                                                   uint32_t *__restrict__ share_off)
+{
+    const int nb = 1 << node_shift;
+    for (int item = first; item < n_shares; item += stride) {
+        const DenseShare sh = locate_share<GATHER>(lds, item, n_dense, list, tile_off, tiles);
+        const int node0 = sh.b.bucket << node_shift;
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = 0;
+        __syncthreads();
+        for_share<GATHER>(lds, sh, staged, [&](int2 v) { atomicAdd(&lds.cnt[v.y - node0], 1u); });
+        __syncthreads();
+        uint32_t *total = node_cnt + (size_t)lds.desc * 1024;
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads) {
+            const uint32_t c = lds.cnt[i];
+            share_off[(size_t)item * 1024 + i] = c ? atomicAdd(&total[i], c) : 0u;
+        }
+    }
+}
+
+// dense_place: row starts from the summed counters (share 0 of a bucket also publishes rowptr and the hub lists), then every edge
+// of the share goes to start + share offset + LDS cursor
+template <bool GATHER>
+__device__ __forceinline__ void dense_place_shares(DenseLds &lds, int first, int stride, const int2 *__restrict__ staged,
+                                                   const uint32_t *__restrict__ tile_off, int tiles, int node_shift, int64_t N, int n_dense,
+                                                   int n_shares, const DenseBucket *__restrict__ list, const uint32_t *__restrict__ node_cnt,
+                                                   const uint32_t *__restrict__ share_off, int32_t *__restrict__ col, const RowOutputs &o)
+{
+    const int nb = 1 << node_shift;
+    for (int item = first; item < n_shares; item += stride) {
+        const DenseShare sh = locate_share<GATHER>(lds, item, n_dense, list, tile_off, tiles);
+        const int node0 = sh.b.bucket << node_shift;
+        const uint32_t *total = node_cnt + (size_t)lds.desc * 1024;
+        // (the totals were formed by other workgroups' agent-scope atomics: read them past the L1)
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads)
+            lds.cnt[i] = __hip_atomic_load(const_cast<uint32_t *>(total) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        scan_bucket_nodes(lds.cnt, lds.excl, lds.wave_tot, nb, (int64_t)node0, N, sh.b.base, sh.b.n, sh.index == 0, o);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = lds.excl[i] + share_off[(size_t)item * 1024 + i];
+        __syncthreads();
+        for_share<GATHER>(lds, sh, staged, [&](int2 v) { col[sh.b.base + atomicAdd(&lds.cnt[v.y - node0], 1u)] = v.x; });
+    }
+}
+
+// the two steps as launches of their own (SS_CSR_DENSE=launch, and whenever the helper count cannot be established)
+template <bool GATHER>
+__global__ __launch_bounds__(kFinishThreads) void dense_count_kernel(const int2 *__restrict__ staged, const uint32_t *__restrict__ tile_off,
+                                                                     int tiles, int node_shift, const int32_t *__restrict__ dense_count,
+                                                                     const DenseBucket *__restrict__ list, uint32_t *__restrict__ node_cnt,
+                                                                     uint32_t *__restrict__ share_off)
+{
+    __shared__ DenseLds lds;
+    dense_count_shares<GATHER>(lds, blockIdx.x, gridDim.x, staged, tile_off, tiles, node_shift, dense_count[0], dense_count[1], list, node_cnt,
+                               share_off);
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(kFinishThreads) void dense_place_kernel(const int2 *__restrict__ staged, const uint32_t *__restrict__ tile_off,
+                                                                     int tiles, int node_shift, int64_t N, const int32_t *__restrict__ dense_count,
+                                                                     const DenseBucket *__restrict__ list, const uint32_t *__restrict__ node_cnt,
+                                                                     const uint32_t *__restrict__ share_off, int32_t *__restrict__ col, RowOutputs o)
+{
+    __shared__ DenseLds lds;
+    dense_place_shares<GATHER>(lds, blockIdx.x, gridDim.x, staged, tile_off, tiles, node_shift, N, dense_count[0], dense_count[1], list,
+                               node_cnt, share_off, col, o);
+}
+
+// ---- the same two steps by HELPER workgroups of the finish launch itself (default) ------------------------------------------
+// Two launches that find nothing to do cost ~4.5 us each on an unskewed graph (2 % of a build + query step at ogbl-collab size).
+// Instead the finish launch carries `helpers` extra workgroups (blockIdx >= the number of fine buckets): a helper waits until every
+// bucket workgroup has decided (count[2], bumped right after a bucket's size is known), leaves if nothing was registered, and
+// otherwise runs the count step over its shares, meets the other helpers at a counter barrier (count[3]) and runs the place step.
+// No deadlock whatever the dispatch order: bucket workgroups never wait for anybody, and the host sizes `helpers` to at most HALF
+// the workgroups of this kernel the device can hold, so waiting helpers can never occupy every slot the bucket workgroups (or the
+// helpers still to be dispatched) need.  Hand-offs follow cdna_hip_programming.md Guideline 16: producer stores -> barrier ->
+// lane-0 agent release fence -> s_waitcnt vmcnt(0) -> relaxed agent atomic; consumer relaxed poll -> agent acquire fence -> barrier.
+// wave 0 polls the sum of `words` counters `stride` ints apart until it reaches `target`; everybody leaves behind an acquire
+__device__ __forceinline__ void wait_for_count(int32_t *first, int words, int stride, int target)
+{
+    if (threadIdx.x < kWave) {
+        long spins = 0;
+        for (;;) {
+            int v = (int)threadIdx.x < words ? __hip_atomic_load(first + stride * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (v >= target) break;  // wave-uniform
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1L << 26)) __builtin_trap();  // (minutes: a launch error instead of a hang if the protocol is ever broken)
+        }
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+template <bool GATHER>
+__device__ __forceinline__ void dense_helper(DenseLds &lds, int helper, int n_buckets, const int2 *__restrict__ staged,
+                                             const uint32_t *__restrict__ tile_off, int tiles, int node_shift, int64_t N,
+                                             int32_t *__restrict__ col, const RowOutputs &o, const DenseArgs &dense)
+{
+    wait_for_count(&dense.count[kArriveBase], kArriveWords, 16, n_buckets);
+    const int n_dense = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n_shares = __hip_atomic_load(&dense.count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n_shares == 0) return;  // every unskewed graph
+    dense_count_shares<GATHER>(lds, helper, dense.helpers, staged, tile_off, tiles, node_shift, n_dense, n_shares, dense.list, dense.node_cnt,
+                               dense.share_off);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&dense.count[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    wait_for_count(&dense.count[3], 1, 0, dense.helpers);
+    dense_place_shares<GATHER>(lds, helper, dense.helpers, staged, tile_off, tiles, node_shift, N, n_dense, n_shares, dense.list,
+                               dense.node_cnt, dense.share_off, col, o);
+}
+
+static_assert(sizeof(DenseLds) <= sizeof(int32_t) * kFinishCap, "the helpers' LDS aliases the finish step's col image");
+
+__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__restrict__ staged, const unsigned long long *__restrict__ fine_base,
+                                                                int node_shift, int64_t N, int32_t *__restrict__ col, RowOutputs o, DenseArgs dense,
+                                                                int64_t n_buckets)
+{
+    __shared__ FinishLds lds;
+    if ((int64_t)blockIdx.x >= n_buckets) {  // helper workgroup (see dense_helper)
+        dense_helper<false>(*reinterpret_cast<DenseLds *>(lds.image), (int)(blockIdx.x - n_buckets), (int)n_buckets, staged, nullptr, 0, node_shift,
+                            N, col, o, dense);
+        return;
+    }
+    const unsigned long long seg_lo = fine_base[blockIdx.x], seg_hi = fine_base[blockIdx.x + 1];
+    const uint32_t seg_n = (uint32_t)(seg_hi - seg_lo);
+    finish_bucket(ContiguousEdges{staged, seg_lo, seg_n}, lds, seg_lo, seg_n, node_shift, N, col, o, dense);
+}
+
+
 __global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int2 *__restrict__ staged, const uint32_t *__restrict__ tile_off,
                                                                        const unsigned long long *__restrict__ tile_max, int tiles, int keys,
-                                                                       int node_shift, int64_t N, int64_t *__restrict__ rowptr,
-                                                                       int32_t *__restrict__ col, unsigned long long *__restrict__ n_self,
-                                                                       int hub_threshold, int32_t *__restrict__ hub_rows,
-                                                                       int32_t *__restrict__ hub_count, int32_t *__restrict__ mega_rows,
-                                                                       int32_t *__restrict__ mega_count)
+                                                                       int node_shift, int64_t N, int32_t *__restrict__ col,
+                                                                       unsigned long long *__restrict__ n_self, RowOutputs o, DenseArgs dense)
 {
     __shared__ FinishLds lds;
     __shared__ uint32_t seg[kMaxTiles];
@@ -707,6 +1017,11 @@ __global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int
     __shared__ int n_long_s;
     __shared__ unsigned long long red_base[kFinishThreads / kWave], red_max[kFinishThreads / kWave];
     __shared__ uint32_t red_n[kFinishThreads / kWave];
+    if ((int)blockIdx.x >= keys) {  // helper workgroup (see dense_helper)
+        dense_helper<true>(*reinterpret_cast<DenseLds *>(lds.image), (int)blockIdx.x - keys, keys, staged, tile_off, tiles, node_shift, N, col, o,
+                           dense);
+        return;
+    }
     const uint32_t *row0 = tile_off + (int64_t)blockIdx.x * tiles, *row1 = row0 + tiles;
     unsigned long long base = 0, mx = 0;
     uint32_t n = 0;
@@ -746,19 +1061,51 @@ __global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int
     }
     if (threadIdx.x == 0) {
         if (blockIdx.x == 0) *n_self = mx;
-        if ((int)blockIdx.x == keys - 1) rowptr[N] = (int64_t)(base + n);  // the last bucket ends the edge list
+        if ((int)blockIdx.x == keys - 1) o.rowptr[N] = (int64_t)(base + n);  // the last bucket ends the edge list
     }
     const uint32_t avg_run = n / (uint32_t)tiles;  // workgroup-uniform
     const int n_long = n_long_s <= kLongCap ? n_long_s : 0;  // (red_* were written behind a barrier: n_long_s is final here)
     if (avg_run < 11)
-        finish_bucket(GatheredEdges<16>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
-                      mega_rows, mega_count);
+        finish_bucket(GatheredEdges<16>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, col, o, dense);
     else if (avg_run < 22)
-        finish_bucket(GatheredEdges<32>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
-                      mega_rows, mega_count);
+        finish_bucket(GatheredEdges<32>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, col, o, dense);
     else
-        finish_bucket(GatheredEdges<64>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, rowptr, col, hub_threshold, hub_rows, hub_count,
-                      mega_rows, mega_count);
+        finish_bucket(GatheredEdges<64>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, col, o, dense);
+}
+
+
+}  // namespace ss
+
+namespace ss {
+
+// helper workgroups a finish launch may carry: at most HALF the workgroups of that kernel the device can hold at once (see
+// dense_helper for why that bound excludes a deadlock), at most kDenseHelpers; 0 = use the stand-alone dense launches
+constexpr int kDenseHelpers = 256;
+template <typename Kernel>
+int helper_budget(Kernel kernel)
+{
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kFinishThreads, 0) != hipSuccess) return 0;
+    const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
+    const int64_t h = slots / 2 < kDenseHelpers ? slots / 2 : kDenseHelpers;
+    return (int)(h > 0 ? h : 0);
+}
+
+inline int dense_helpers(bool gather)
+{
+    static const bool launches = getenv("SS_CSR_DENSE") && !strcmp(getenv("SS_CSR_DENSE"), "launch");
+    // per device: a process may drive GPUs of different sizes
+    static int cache[2][64];
+    static bool known[2][64];
+    int dev = 0;
+    if (launches || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!known[gather][dev]) {
+        cache[gather][dev] = gather ? helper_budget(finish_gather_kernel) : helper_budget(finish_kernel);
+        known[gather][dev] = true;
+    }
+    return cache[gather][dev];
 }
 
 }  // namespace ss
@@ -794,14 +1141,27 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     const Workspace w = carve(p, E, workspace);
     ProfileSpan span(stream, SS_PROF_CSR);  // all launches of this build
     unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
+    const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count};
+    // the dense steps loop over the registered shares: no more workgroups than shares can exist
+    const int64_t share_cap = max_dense_shares(E);
+    const unsigned dense_grid = (unsigned)(share_cap < kDenseGrid ? share_cap : kDenseGrid);
+    int helpers = dense_helpers(p.gather);
+    if ((int64_t)helpers > share_cap) helpers = (int)share_cap;
+    const DenseArgs dense = {w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, helpers};
 
     if (p.gather) {  // <= 256 fine buckets and <= kMaxTiles tiles: two launches, no counting pass, no scan kernels
         hipLaunchKernelGGL(tile_sort_kernel, dim3(p.tiles), dim3(kSortThreads), 0, stream, src, dst, E, N, p.shift1, p.keys1, p.tiles, w.staged_a,
-                           w.tile_off, w.tile_max, err_flag, hub_count, mega_count);
+                           w.tile_off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count);
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(finish_gather_kernel, dim3((unsigned)p.fine_buckets), dim3(kFinishThreads), 0, stream, w.staged_a, w.tile_off,
-                           w.tile_max, p.tiles, p.keys1, p.node_shift, N, rowptr, col, n_self, (int)hub_threshold, hub_rows, hub_count,
-                           mega_rows, mega_count);
+        hipLaunchKernelGGL(finish_gather_kernel, dim3((unsigned)(p.fine_buckets + helpers)), dim3(kFinishThreads), 0, stream, w.staged_a,
+                           w.tile_off, w.tile_max, p.tiles, p.keys1, p.node_shift, N, col, n_self, rows_out, dense);
+        SS_LAUNCH_CHECK();
+        if (helpers) return SS_OK;
+        hipLaunchKernelGGL(dense_count_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, w.staged_a, w.tile_off, p.tiles,
+                           p.node_shift, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(dense_place_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, w.staged_a, w.tile_off, p.tiles,
+                           p.node_shift, N, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, col, rows_out);
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
@@ -809,7 +1169,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     PassArgs a1 = {};
     a1.src = src; a1.dst = dst; a1.E = E; a1.N = N; a1.slice = p.slice1; a1.shift = p.shift1; a1.keys = p.keys1;
     hipLaunchKernelGGL(count_keys_kernel<false>, dim3(p.blocks1), dim3(kThreads), 0, stream, a1, w.counts1, err_flag, n_self, hub_count,
-                       mega_count);
+                       mega_count, w.dense_count);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_block_counts_kernel, dim3((p.keys1 + 3) / 4), dim3(kThreads), 0, stream, w.counts1, p.blocks1, p.keys1, w.base1);
     SS_LAUNCH_CHECK();
@@ -828,7 +1188,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
         const int64_t buckets2 = p.three_pass ? p.groups3 : p.fine_buckets;  // buckets that exist after pass 2
         const unsigned blocks2 = (unsigned)(p.keys1 * p.parts2);
         hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks2), dim3(kThreads), 0, stream, a2, w.counts2, (int32_t *)nullptr,
-                           (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+                           (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(scan_sub_counts_kernel, dim3(p.keys1), dim3(kThreads), 0, stream, w.counts2, p.keys2, p.parts2, w.base1,
                            w.fine_base, buckets2, p.keys1);
@@ -846,7 +1206,7 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
             a3.parts = p.parts3;
             const unsigned blocks3 = (unsigned)(p.groups3 * p.parts3);
             hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks3), dim3(kThreads), 0, stream, a3, w.counts3, (int32_t *)nullptr,
-                               (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+                               (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
             SS_LAUNCH_CHECK();
             hipLaunchKernelGGL(scan_sub_counts_kernel, dim3((unsigned)p.groups3), dim3(kThreads), 0, stream, w.counts3, p.keys3, p.parts3,
                                w.fine_base, w.fine_base3, p.fine_buckets, (int)p.groups3);
@@ -859,8 +1219,15 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
         }
     }
     // ---- finish ----
-    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p.fine_buckets), dim3(kFinishThreads), 0, stream, final_staged, fine_base, p.node_shift,
-                       N, rowptr, col, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count);
+    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)(p.fine_buckets + helpers)), dim3(kFinishThreads), 0, stream, final_staged, fine_base,
+                       p.node_shift, N, col, rows_out, dense, p.fine_buckets);
+    SS_LAUNCH_CHECK();
+    if (helpers) return SS_OK;
+    hipLaunchKernelGGL(dense_count_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, final_staged, (const uint32_t *)nullptr, 0,
+                       p.node_shift, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dense_place_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, final_staged, (const uint32_t *)nullptr, 0,
+                       p.node_shift, N, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, col, rows_out);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

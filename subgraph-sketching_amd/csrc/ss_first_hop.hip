@@ -223,9 +223,10 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
     __shared__ EstimatorLds lds;
     __shared__ __attribute__((aligned(16))) uint32_t hll_row[256];
     __shared__ uint32_t mh_row[PPL * kWave];
-    __shared__ int s_last;
+    __shared__ int s_last, s_m;
     const int n_hubs = *g.hub_count;
     const int n_mega = g.mega_count ? g.mega_count[0] : 0;
+    const int n_slices = g.mega_count ? g.mega_count[1] : 0;
     if ((int)blockIdx.x >= n_hubs && n_mega == 0) return;  // the common case (no hub rows) costs two scalar loads per workgroup
     const bool want_cards = DO_HLL && cards_out != nullptr;
     EstimatorTables est;
@@ -251,7 +252,18 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
 #pragma unroll
         for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
         // slice = the same walk over nb + lo with the degree counted from lo (slot deg - lo is the implicit self loop)
-        first_hop_walk<PPL, DO_MH, DO_HLL>(nb + lo, deg - lo, hi - lo, i, wave, kHubWaves, p, a, b, acc, hll_row, lane);
+        if (DO_HLL) first_hop_walk<PPL, false, true>(nb + lo, deg - lo, hi - lo, i, wave, kHubWaves, p, a, b, acc, hll_row, lane);
+        // MinHash: the two-phase walk (ss_walks.hpp: 4-5 instead of 10 VALU per neighbour and permutation) over this wavefront's
+        // batches; a wavefront whose share is ambiguous (duplicated minimum, key collision) redoes its share exactly
+        if (DO_MH && wave * kWave < hi - lo) {  // (wave-uniform) the wavefront has at least one batch
+            const bool amb = kForceExactFirstHop ||
+                             first_hop_minhash_fast<PPL>(nb + lo, deg - lo, hi - lo, i, a, b, acc, lane, wave, kHubWaves);
+            if (__any(amb)) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
+                first_hop_walk<PPL, true, false>(nb + lo, deg - lo, hi - lo, i, wave, kHubWaves, p, a, b, acc, hll_row, lane);
+            }
+        }
         if (DO_MH) {
 #pragma unroll
             for (int q = 0; q < PPL; ++q) atomicMin(&mh_row[lane + kWave * q], acc[q]);
@@ -296,16 +308,22 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
     // ---- mega rows: slices of SS_MEGA_SLICE neighbours spread over all workgroups, combined by the last one to finish
     // (see propagate_hub_kernel); scratch layout per slice: MinHash u32[P] (P <= 256: within the first 1024 B ... P = 128
     // uses 512 B) then the packed HLL row at byte 512
-    for (int m = 0; m < n_mega; ++m) {
+    // one list of the slices of ALL mega rows, continuing the round robin of the hub rows (see propagate_hub_kernel)
+    for (int gs = (int)((blockIdx.x + gridDim.x - (unsigned)n_hubs % gridDim.x) % gridDim.x); gs < n_slices; gs += gridDim.x) {
+        for (int t = threadIdx.x; t < n_mega; t += kHubThreads) {
+            const int4 d = reinterpret_cast<const int4 *>(g.mega_rows)[t];
+            if (gs >= d.y && gs < d.y + d.z) s_m = t;
+        }
+        __syncthreads();
+        const int m = s_m;
         const int4 e = reinterpret_cast<const int4 *>(g.mega_rows)[m];
         const int64_t i = e.x;
-        if (!g.owns(i)) continue;
+        if (!g.owns(i)) { __syncthreads(); continue; }  // workgroup-uniform
         const int64_t rb = g.rowptr[i];
         const int deg = (int)(g.rowptr[i + 1] - rb);
         const int total = deg + (i < n_self ? 1 : 0);
-        // global slice g = e.y + sl belongs to workgroup g % gridDim.x: the slices of ALL mega rows are dealt round robin
-        // (dealing each row's slices from workgroup 0 would give the low-numbered workgroups one slice of every row)
-        for (int sl = (int)((blockIdx.x + gridDim.x - (unsigned)e.y % gridDim.x) % gridDim.x); sl < e.z; sl += gridDim.x) {
+        {
+            const int sl = gs - e.y;
             const int lo = sl * SS_MEGA_SLICE < total ? sl * SS_MEGA_SLICE : total;
             const int hi = lo + SS_MEGA_SLICE < total ? lo + SS_MEGA_SLICE : total;
             walk(i, g.col + rb, deg, lo, hi);
@@ -325,26 +343,41 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
                 if (s_last) reset_ticket(&g.mega_rows[4 * m + 3]);
             }
             __syncthreads();
-            if (s_last) {
-                if (wave == 0) {
-                    uint32_t mh[PPL], regs = 0u;
+            if (s_last) {  // workgroup-uniform.  All 16 waves read the slots (wave w: slots w, w + 16, ...), combined through the
+                           // LDS rows of the walk (which the barrier above has released), wave 0 stores
+                uint32_t mh[PPL], regs = 0u;
 #pragma unroll
-                    for (int q = 0; q < PPL; ++q) mh[q] = 0xFFFFFFFFu;
-                    for (int s2 = 0; s2 < e.z; ++s2) {
-                        const uint8_t *part = g.mega_scratch + (int64_t)(e.y + s2) * kMegaSlot;
-                        if (DO_MH) {
+                for (int q = 0; q < PPL; ++q) mh[q] = 0xFFFFFFFFu;
+                for (int s2 = wave; s2 < e.z; s2 += kHubWaves) {
+                    const uint8_t *part = g.mega_scratch + (int64_t)(e.y + s2) * kMegaSlot;
+                    if (DO_MH) {
 #pragma unroll
-                            for (int q = 0; q < PPL; ++q) {
-                                const uint32_t v = coherent_load(reinterpret_cast<const uint32_t *>(part) + lane + kWave * q);
-                                mh[q] = v < mh[q] ? v : mh[q];
-                            }
-                        }
-                        if (DO_HLL) {
-                            const uint32_t v = coherent_load(reinterpret_cast<const uint32_t *>(part + kMegaHllOffset) + lane);
-                            regs = pk_max_u16(regs & 0x00FF00FFu, v & 0x00FF00FFu) | pk_max_u16(regs & 0xFF00FF00u, v & 0xFF00FF00u);
+                        for (int q = 0; q < PPL; ++q) {
+                            const uint32_t v = coherent_load(reinterpret_cast<const uint32_t *>(part) + lane + kWave * q);
+                            mh[q] = v < mh[q] ? v : mh[q];
                         }
                     }
-                    finish(i, mh, regs);
+                    if (DO_HLL) {
+                        const uint32_t v = coherent_load(reinterpret_cast<const uint32_t *>(part + kMegaHllOffset) + lane);
+                        regs = pk_max_u16(regs & 0x00FF00FFu, v & 0x00FF00FFu) | pk_max_u16(regs & 0xFF00FF00u, v & 0xFF00FF00u);
+                    }
+                }
+                if (threadIdx.x < 256) hll_row[threadIdx.x] = 0u;
+                if (threadIdx.x < P) mh_row[threadIdx.x] = 0xFFFFFFFFu;
+                __syncthreads();
+                if (DO_MH) {
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) atomicMin(&mh_row[lane + kWave * q], mh[q]);
+                }
+                if (DO_HLL) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) atomicMax(&hll_row[4 * lane + k], (regs >> (8 * k)) & 0xFFu);
+                }
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) mh[q] = DO_MH ? mh_row[lane + kWave * q] : 0u;
+                    finish(i, mh, DO_HLL ? pack_hll_quad(hll_row, lane) : 0u);
                 }
             }
             __syncthreads();

@@ -234,7 +234,8 @@ extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, 
     const unsigned blocks = (unsigned)((g.rows() + rows_per_block - 1) / rows_per_block);
     // 4 workgroups are resident per CU (126 VGPRs); three times that many balance the tail (bench graph: 4 / 8 / 12 / 16 / all
     // 14 742 workgroups: 158.7 / 153-157 / 150-153 / 153.5 / 163 us)
-    static const int wg_per_cu = getenv("SS_FUSED_WG_PER_CU") ? atoi(getenv("SS_FUSED_WG_PER_CU")) : 12;
+    static const int wg_per_cu_env = getenv("SS_FUSED_WG_PER_CU") ? atoi(getenv("SS_FUSED_WG_PER_CU")) : 0;
+    static const int wg_per_cu = (wg_per_cu_env > 0 && wg_per_cu_env <= 64) ? wg_per_cu_env : 12;  // (a bad value falls back to the default)
     const unsigned grid = blocks < (unsigned)(256 * wg_per_cu) ? blocks : (unsigned)(256 * wg_per_cu);
     {
         ProfileSpan span(s, SS_PROF_FUSED);

@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
         u_next = links[2 * q_raw];
         v_next = links[2 * q_raw + 1];
     }
-    for (; q_raw - (threadIdx.x / kRow) < B; q_raw += stride) {  // workgroup-uniform trip count (no barrier inside, kept simple)
+    // the trip count is WORKGROUP-UNIFORM (q_raw - group index is the same for every thread): stage_tables(), which contains a
+    // __syncthreads(), runs inside the first iteration and relies on exactly that
+    for (; q_raw - (threadIdx.x / kRow) < B; q_raw += stride) {
     const bool q_ok = q_raw < B;
     const int64_t q = q_ok ? q_raw : B - 1;
     int64_t u = q_ok ? u_next : 0, v = q_ok ? v_next : 0;

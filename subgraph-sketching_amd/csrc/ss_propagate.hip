@@ -154,9 +154,10 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
     __shared__ EstimatorLds lds;
     __shared__ u32x4 part_mh[kHubWaves][CM];
     __shared__ u32x4 part_hll[kHubWaves][CH];
-    __shared__ int s_last;
+    __shared__ int s_last, s_m;
     const int n_hubs = *g.hub_count;
     const int n_mega = g.mega_count ? g.mega_count[0] : 0;
+    const int n_slices = g.mega_count ? g.mega_count[1] : 0;
     if ((int)blockIdx.x >= n_hubs && n_mega == 0) return;  // the common case (no hub rows) costs two scalar loads per workgroup
     const bool want_cards = cards_out != nullptr && hll_out != nullptr;
     EstimatorTables est;
@@ -167,16 +168,25 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
 
     // all 16 waves walk the neighbours t in [lo, hi) of row i; wave 0 ends up with the combined partial rows
     // (MinHash chunk `lane` in lanes 0..31, HLL chunk `lane - 32` in lanes 32..47)
+    // (wave w takes the CONTIGUOUS 64-neighbour chunks w, w + 16, ... of [lo, hi): ids by one coalesced load per chunk, handed
+    // out with v_readlane (MinHash) / DPP row broadcasts (HLL: 16 neighbours per lane group) -- one round trip per chunk instead
+    // of the generic walk's two per batch of four)
     auto walk = [&](int64_t i, const int32_t *nb, int deg, int lo, int hi, u32x4 &mh_acc, u32x4 &hll_acc) {
         if (mh_out) {
             const int sg = lane >> 5, c = lane & 31;
-            u32x4 acc = minhash_walk(mh_in, nb, deg, hi, i, lo + wave * 2 + sg, kHubWaves * 2, P, c);
+            u32x4 acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            for (int b = lo + wave * kWave; b < hi; b += kHubWaves * kWave)  // wave-uniform
+                acc = min4(acc, minhash_chunk64(mh_in, nb + b, deg - b, hi - b < kWave ? hi - b : kWave, i, lane));
             acc = min4(acc, shfl_xor4(acc, 32));
             if (sg == 0) part_mh[wave][c] = acc;
         }
         if (hll_out) {
             const int sg = lane >> 4, c = lane & 15;
-            u32x4 acc = hll_walk(hll_in, nb, deg, hi, i, lo + wave * 4 + sg, kHubWaves * 4, M, c);
+            u32x4 acc = {0u, 0u, 0u, 0u};
+            for (int b = lo + wave * kWave; b < hi; b += kHubWaves * kWave) {
+                const int bg = b + kRow * sg;  // this lane group's 16 neighbours of the chunk
+                acc = bytemax16(acc, hll_walk_first16(hll_in, nb + bg, deg - bg, hi - bg, i, c));
+            }
             acc = bytemax16(acc, shfl_xor4(acc, 16));
             acc = bytemax16(acc, shfl_xor4(acc, 32));
             if (sg == 0) part_hll[wave][c] = acc;
@@ -230,16 +240,25 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
     // ---- mega rows: every workgroup takes slices of SS_MEGA_SLICE neighbours of every mega row; the partial rows go
     // through mega_scratch and the workgroup that finishes a row's LAST slice (ticket counter) combines them.  A row
     // with a million neighbours is spread over the whole chip instead of being one workgroup's serial walk.
-    for (int m = 0; m < n_mega; ++m) {
+    // The slices of ALL mega rows form one list (slice s of the row with first slice f is global slice f + s) that continues the
+    // round robin of the hub rows above: hub row h went to workgroup h % grid, global slice gs goes to (n_hubs + gs) % grid.
+    // Whose slice gs is: every thread looks at some descriptors (a per-row loop over all mega rows cost every workgroup three
+    // dependent loads per ROW, slices or not).
+    for (int gs = (int)((blockIdx.x + gridDim.x - (unsigned)n_hubs % gridDim.x) % gridDim.x); gs < n_slices; gs += gridDim.x) {
+        for (int t = threadIdx.x; t < n_mega; t += kHubThreads) {
+            const int4 d = reinterpret_cast<const int4 *>(g.mega_rows)[t];
+            if (gs >= d.y && gs < d.y + d.z) s_m = t;
+        }
+        __syncthreads();
+        const int m = s_m;
         const int4 e = reinterpret_cast<const int4 *>(g.mega_rows)[m];  // {row, first slice, slices, ticket}
         const int64_t i = e.x;
-        if (!g.owns(i)) continue;
+        if (!g.owns(i)) { __syncthreads(); continue; }  // workgroup-uniform
         const int64_t rb = g.rowptr[i];
         const int deg = (int)(g.rowptr[i + 1] - rb);
         const int total = deg + (i < n_self ? 1 : 0);
-        // global slice g = e.y + sl belongs to workgroup g % gridDim.x: the slices of ALL mega rows are dealt round robin
-        // (dealing each row's slices from workgroup 0 would give the low-numbered workgroups one slice of every row)
-        for (int sl = (int)((blockIdx.x + gridDim.x - (unsigned)e.y % gridDim.x) % gridDim.x); sl < e.z; sl += gridDim.x) {
+        {
+            const int sl = gs - e.y;
             const int lo = sl * SS_MEGA_SLICE < total ? sl * SS_MEGA_SLICE : total;
             const int hi = lo + SS_MEGA_SLICE < total ? lo + SS_MEGA_SLICE : total;
             u32x4 mh_acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hll_acc = {0u, 0u, 0u, 0u};
@@ -257,14 +276,26 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
                 if (s_last) reset_ticket(&g.mega_rows[4 * m + 3]);  // every slice has arrived: ready for the next hop
             }
             __syncthreads();
-            if (s_last) {
+            if (s_last) {  // workgroup-uniform.  All 16 waves read the slots (wave w: slots w, w + 16, ...: a row of 70 000
+                           // neighbours has 69 of them, one wave reading them in turn was a 50 us tail), wave 0 combines and stores
+                u32x4 mh_all = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hll_all = {0u, 0u, 0u, 0u};
+                for (int q = wave; q < e.z; q += kHubWaves) {
+                    const uint8_t *part = g.mega_scratch + (int64_t)(e.y + q) * kMegaSlot;
+                    if (mh_out && lane < CM) mh_all = min4(mh_all, coherent_load4(part + 16 * lane));
+                    if (hll_out && lane >= 32 && lane < 32 + CH)
+                        hll_all = bytemax16(hll_all, coherent_load4(part + kMegaHllOffset + 16 * (lane - 32)));
+                }
+                if (mh_out && lane < CM) part_mh[wave][lane] = mh_all;
+                if (hll_out && lane >= 32 && lane < 32 + CH) part_hll[wave][lane - 32] = hll_all;
+                __syncthreads();
                 if (wave == 0) {
-                    u32x4 mh_all = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hll_all = {0u, 0u, 0u, 0u};
-                    for (int q = 0; q < e.z; ++q) {
-                        const uint8_t *part = g.mega_scratch + (int64_t)(e.y + q) * kMegaSlot;
-                        if (mh_out && lane < CM) mh_all = min4(mh_all, coherent_load4(part + 16 * lane));
-                        if (hll_out && lane >= 32 && lane < 32 + CH)
-                            hll_all = bytemax16(hll_all, coherent_load4(part + kMegaHllOffset + 16 * (lane - 32)));
+                    if (mh_out && lane < CM) {
+#pragma unroll
+                        for (int w = 1; w < kHubWaves; ++w) mh_all = min4(mh_all, part_mh[w][lane]);
+                    }
+                    if (hll_out && lane >= 32 && lane < 32 + CH) {
+#pragma unroll
+                        for (int w = 1; w < kHubWaves; ++w) hll_all = bytemax16(hll_all, part_hll[w][lane - 32]);
                     }
                     finish(i, mh_all, hll_all);
                 }

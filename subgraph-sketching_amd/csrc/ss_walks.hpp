@@ -74,6 +74,33 @@ __device__ __forceinline__ u32x4 minhash_walk128(const uint32_t *__restrict__ mh
     return acc;
 }
 
+// hub / mega rows (propagate_hub_kernel): ONE wavefront folds a CONTIGUOUS chunk of <= 64 neighbours, nb[0 .. total) with
+// nb[t >= deg] = the implicit self loop.  Ids arrive with one coalesced load and are handed out with v_readlane, the two
+// 32-lane halves take alternating neighbours, four row loads per lane are requested before the first is folded (the generic
+// batched walk pays a second, dependent, round trip per batch for its broadcast id loads)
+__device__ __forceinline__ u32x4 minhash_chunk64(const uint32_t *__restrict__ mh_in, const int32_t *__restrict__ nb, int deg, int total,
+                                                 int64_t self_row, int lane)
+{
+    const int sg = lane >> 5, c = lane & 31;
+    const int my_nb = lane < deg ? nb[lane] : 0;
+    u32x4 acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (int t0 = 0; t0 < total; t0 += 8) {  // wave-uniform trip count
+        u32x4 x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s0 = __builtin_amdgcn_readlane(my_nb, (t0 + 2 * k) & (kWave - 1));
+            const int s1 = __builtin_amdgcn_readlane(my_nb, (t0 + 2 * k + 1) & (kWave - 1));
+            const int t = t0 + 2 * k + sg;
+            const int64_t j = t < deg ? (int64_t)(sg ? s1 : s0) : self_row;
+            x[k] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (t < total) x[k] = *reinterpret_cast<const u32x4 *>(mh_in + j * 128 + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = min4(acc, x[k]);
+    }
+    return acc;
+}
+
 // byte-wise max over the same neighbour walk of HLL chunk c; even / odd bytes accumulated as packed u16
 __device__ __forceinline__ u32x4 hll_walk(const uint8_t *__restrict__ hll_in, const int32_t *__restrict__ nb, int deg, int total,
                                           int64_t self_row, int first, int stride, int M, int c)
@@ -233,9 +260,13 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
     return d;
 }
 
+// first_batch / batch_stride: the wavefront takes the 64-neighbour batches first_batch, first_batch + batch_stride, ... of the row
+// (first_hop_hub_kernel: 16 wavefronts share a hub row or a slice of a mega row; each one's minimum is exact -- or flagged --
+// on its own, the workgroup combines them with an exact min)
 template <int PPL>
 __device__ __forceinline__ bool first_hop_minhash_fast(const int32_t *__restrict__ nb, int deg, int total, int64_t self_row,
-                                                       const uint64_t (&a)[PPL], const uint64_t (&b)[PPL], uint32_t (&acc)[PPL], int lane)
+                                                       const uint64_t (&a)[PPL], const uint64_t (&b)[PPL], uint32_t (&acc)[PPL], int lane,
+                                                       int first_batch = 0, int batch_stride = 1)
 {
     uint32_t m1[PPL], m2[PPL], h1_lo[PPL], h1_hi[PPL], a_lo[PPL], b8[PPL];
 #pragma unroll
@@ -246,7 +277,7 @@ __device__ __forceinline__ bool first_hop_minhash_fast(const int32_t *__restrict
         b8[q] = (uint32_t)b[q] + 8u;
     }
     bool seen_self = false;  // the row lists its own node explicitly (graphs that already carry self loops)
-    for (int base = 0; base < total; base += kWave) {
+    for (int base = first_batch * kWave; base < total; base += batch_stride * kWave) {
         const int t = base + lane;
         const int64_t nid = t < deg ? (int64_t)nb[t] : self_row;
         const uint64_t hv = hash_u64((uint64_t)(nid + 1));

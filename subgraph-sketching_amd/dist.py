@@ -50,10 +50,13 @@ def exchange_blocks_p2p(full, rank, world, per, group=None):
     (wait on all of them); synchronous backends (gloo on CPU tensors) complete before returning."""
     ops = []
     mine = full[rank * per:(rank + 1) * per]
+    # `rank` / `world` are ranks WITHIN `group`; P2POp's positional peer is a GLOBAL rank (ADVICE r2): translate, so that a
+    # sub-group (one node of a multi-node job) exchanges with its own members
+    to_global = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     for step in range(1, world):
         dst, src = (rank + step) % world, (rank - step) % world
-        ops.append(dist.P2POp(dist.isend, mine, dst, group))
-        ops.append(dist.P2POp(dist.irecv, full[src * per:(src + 1) * per], src, group))
+        ops.append(dist.P2POp(dist.isend, mine, to_global(dst), group))
+        ops.append(dist.P2POp(dist.irecv, full[src * per:(src + 1) * per], to_global(src), group))
     reqs = dist.batch_isend_irecv(ops) if ops else []
     for r in reqs:
         r.wait()

@@ -140,6 +140,8 @@ class _DeferredErrors(object):
             if synchronize:
                 torch.cuda.synchronize(torch.device(key))
             if int(flag[0]):
+                if not synchronize:  # the word is only cleared once nothing in flight can still write it
+                    torch.cuda.synchronize(torch.device(key))
                 flag.zero_()
                 calls, self._calls = ', '.join(self._calls), []
                 raise IndexError(f'an earlier call on this engine was given node ids outside its num_nodes (reported late: '
@@ -311,7 +313,7 @@ def load_sketches(path, device=None, expect=None):
         table[int(k)] = HopSketch(entry['minhash_u32'].to(device), entry['hll_u8'].to(device), device)
     cached_id = blob.get('hll_tables', 'unknown')
     want = expect.tables_id if isinstance(expect, ElphHashes) else expect
-    if want is not None and cached_id != 'unknown' and cached_id != want:
+    if want is not None and cached_id != 'unknown' and not hll_tables.same_tables(cached_id, want):
         raise ValueError(f'{path} holds cardinalities made with HLL++ tables {cached_id}, this engine uses {want}')
     cards = blob['cards'].to(device)
     return table, (_stamp_tables(cards, cached_id) if cached_id != 'unknown' else cards)
@@ -388,8 +390,11 @@ class LazyMinhash(torch.Tensor):
         if self._real is not None:
             return None
         if self._pending is not None and self._partial is not None:
-            if self._partial_rows + rows.numel() <= self._packed.size(0):
-                self._partial_rows += rows.numel()
+            # ONE row-list launch per table (ELPH's training step: one forward, one batch).  A second reader of the same table
+            # -- the reference's inference loop: one forward, many get_subgraph_features batches -- completes it instead: every
+            # partial launch also pays a hub pass over ALL hub rows, and the pending closure pins the previous hop's table
+            if self._partial_rows == 0 and rows.numel() <= self._packed.size(0):
+                self._partial_rows = rows.numel()
                 self._partial(rows.reshape(-1))
                 return self._packed
         self.resolve()
@@ -641,8 +646,19 @@ class MinhashPropagation(object):
     """drop-in for reference hashing.py:28-35: out[i] = min over in-neighbours (edges j -> i) of x[j];
     rows without an in-edge are 0.  x: int64 [N, P] with values in [0, 2^32)."""
 
-    def __init__(self, csr_cache=None):
+    def __init__(self, csr_cache=None, after_host_copy=None):
+        """after_host_copy: called once a result has been copied back to a CPU caller (the copy has waited for the launches, so
+        the owner's deferred bounds report is final and is raised from the offending call itself)"""
         self._cache = csr_cache or _default_csr_cache
+        self._after_host_copy = after_host_copy
+
+    def _to_caller(self, out, x, device):
+        if x.device == device:
+            return out
+        out = out.to(x.device)
+        if self._after_host_copy is not None:
+            self._after_host_copy()
+        return out
 
     @torch.no_grad()
     def forward(self, x, edge_index):
@@ -686,7 +702,7 @@ class MinhashPropagation(object):
             return LazyMinhash(out_u32)
         out = unpack_minhash(out_u32)
         _tag(out, '_ss_u32', out_u32)
-        return out if x.device == device else out.to(x.device)
+        return self._to_caller(out, x, device)
 
     __call__ = forward
 
@@ -694,12 +710,15 @@ class MinhashPropagation(object):
 class HllPropagation(object):
     """drop-in for reference hashing.py:38-45: out[i] = element-wise max over in-neighbours of x[j]"""
 
-    def __init__(self, csr_cache=None, params_of=None, m=None):
-        """params_of(device) -> _DeviceParams and m: given by the ElphHashes that owns this module; the kernels then also
+    def __init__(self, csr_cache=None, params_of=None, m=None, after_host_copy=None):
+        """after_host_copy: see MinhashPropagation.  params_of(device) -> _DeviceParams and m: given by the ElphHashes that owns this module; the kernels then also
         produce the HLL++ cardinality of every output row (free: the registers are in flight) and ElphHashes.hll_count of
         that very tensor (reference models/elph.py:213) is answered without another pass over the table"""
         self._cache = csr_cache or _default_csr_cache
         self._params_of, self._m = params_of, m
+        self._after_host_copy = after_host_copy
+
+    _to_caller = MinhashPropagation._to_caller
 
     @torch.no_grad()
     def forward(self, x, edge_index):
@@ -740,7 +759,7 @@ class HllPropagation(object):
         _tag(out, '_ss_u8', out_u8)
         if counts is not None:
             _tag(out, '_ss_count', counts)
-        return out if x.device == device else out.to(x.device)
+        return self._to_caller(out, x, device)
 
     __call__ = forward
 
@@ -767,7 +786,7 @@ class ElphHashes(object):
         self.minhash_seed = 1
         self.num_perm = args.minhash_num_perm
         self._csr_cache = _CsrCache(self._bounds)
-        self.minhash_prop = MinhashPropagation(self._csr_cache)
+        self.minhash_prop = MinhashPropagation(self._csr_cache, self._report_after_host_copy)
         # hll params (reference hashing.py:65-81)
         self.p = args.hll_p
         self.m = 1 << self.p
@@ -782,7 +801,7 @@ class ElphHashes(object):
         self.hll_threshold = self.hll_tables.threshold
         self.bias_vector = torch.tensor(self.hll_tables.bias, dtype=torch.float)
         self.estimate_vector = torch.tensor(self.hll_tables.raw_estimate, dtype=torch.float)
-        self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m)
+        self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m, self._report_after_host_copy)
         self._dev_params = {}
         self._dev_perms = {}
         self.fuse_first_hop = True  # compute hop 1 straight from node ids when the fused kernel supports (num_perm, p)
@@ -807,8 +826,14 @@ class ElphHashes(object):
         self.__dict__.update(state)
         self._deferred = _DeferredErrors()
         self._csr_cache = _CsrCache(self._bounds)
-        self.minhash_prop = MinhashPropagation(self._csr_cache)
-        self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m)
+        self.minhash_prop = MinhashPropagation(self._csr_cache, self._report_after_host_copy)
+        self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m, self._report_after_host_copy)
+
+    def _report_after_host_copy(self):
+        """a result has just been copied to a CPU caller (ELPH on CPU tensors): the launches behind it are complete, so a
+        deferred bounds report is final -- raise it from the offending call, as the reference's CPU indexing would"""
+        if self.strict_bounds == 'deferred':
+            self._deferred.raise_if_set()
 
     # ---- host-side helpers -------------------------------------------------------------------------
     @property
@@ -1058,7 +1083,7 @@ class ElphHashes(object):
             cd = torch.zeros((N, h), dtype=torch.float32, device=device)
         else:
             made_with = getattr(cards, '_ss_tables', None)
-            if made_with is not None and made_with != self.tables_id:
+            if made_with is not None and not hll_tables.same_tables(made_with, self.tables_id):
                 raise ValueError(f'cards were estimated with HLL++ tables {made_with}, this engine uses {self.tables_id}: '
                                  f'a feature row would mix two bias tables (rebuild the cache or load the same tables)')
             # ELPH keeps `cards` on the CPU and the reference re-uploads it on every call (hashing.py:274): keep a device

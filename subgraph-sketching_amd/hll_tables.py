@@ -56,6 +56,15 @@ def table_id(tables):
     return f'{tables.provenance}:{h.hexdigest()[:12]}'
 
 
+def same_tables(id_a, id_b):
+    """two table ids name the same NUMBERS: only the digest counts -- the tables served by the datasketch package
+    ('datasketch:<digest>') and by its shipped export ('datasketch-export:<digest>') are bit-identical, and a cache built
+    next to one must load next to the other.  The provenance part is for display."""
+    if id_a is None or id_b is None:
+        return id_a == id_b
+    return str(id_a).rsplit(':', 1)[-1] == str(id_b).rsplit(':', 1)[-1]
+
+
 def _from_datasketch(p):
     from datasketch import HyperLogLogPlusPlus, hyperloglog_const
     tmp = HyperLogLogPlusPlus(p=p)

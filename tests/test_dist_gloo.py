@@ -192,3 +192,31 @@ def _p2p_worker(rank, world, port, per):
 def test_point_to_point_block_exchange(world, per):
     """the direct (link-parallel) form of the per-hop exchange: every rank ends with every block, any world size"""
     mp.spawn(_p2p_worker, args=(world, _free_port(), per), nprocs=world, join=True)
+
+
+def _p2p_subgroup_worker(rank, world, port, per):
+    """ranks {1, 3} and {0, 2} form two sub-groups (group rank != global rank for rank 3 / 2): the exchange must stay inside each"""
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import subgraph_sketching_amd as ssa
+    groups = [dist.new_group([0, 2]), dist.new_group([1, 3])]  # every rank creates every group (torch requirement)
+    group = groups[rank % 2]
+    g_rank, g_world = dist.get_rank(group), dist.get_world_size(group)
+    assert g_world == 2 and g_rank == rank // 2
+    full = torch.full((g_world * per, 2), -1, dtype=torch.int32)
+    full[g_rank * per:(g_rank + 1) * per] = 100 * (rank % 2) + g_rank
+    ssa.dist.exchange_blocks_p2p(full, g_rank, g_world, per, group)
+    want = torch.arange(g_world, dtype=torch.int32).repeat_interleave(per)[:, None].expand(-1, 2) + 100 * (rank % 2)
+    assert torch.equal(full, want), f'rank {rank}: sub-group exchange reached the wrong peers'
+    # RowShard on the sub-group: owned rows and the gathered table follow the GROUP rank
+    shard = ssa.dist.RowShard(10, group)
+    assert (shard.rank, shard.world) == (g_rank, g_world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_point_to_point_block_exchange_in_a_sub_group():
+    """P2POp peers are global ranks; a per-node sub-group must exchange with its own members"""
+    mp.spawn(_p2p_subgroup_worker, args=(4, _free_port(), 5), nprocs=4, join=True)

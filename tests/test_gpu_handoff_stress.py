@@ -64,7 +64,7 @@ def test_mega_row_handoff_under_memory_pressure(regenerated_tables):
     csr.use_inferred_self_loops = True
     assert int(csr.mega_count[0].item()) == N_MEGA
     n_slices = int(csr.mega_count[1].item())
-    assert n_slices >= N_MEGA * (MEGA_DEG // 4096)
+    assert n_slices >= N_MEGA * (MEGA_DEG // ssa._native.MEGA_SLICE)
     rows = torch.from_numpy(mega_nodes).to(dev)
 
     def run(graph_csr, mh_in, hll_in, mh_out, hll_out, cards):

@@ -209,6 +209,10 @@ def test_regenerated_tables_warn_and_are_identified(ssa, caplog, monkeypatch):
     assert tid.startswith('regenerated:') and tid == ht.table_id(ht.load(8, prefer='regenerated'))
     other = t._replace(bias=t.bias + 1e-3)
     assert ht.table_id(other) != tid and ht.table_id(t._replace(provenance='datasketch')) != tid
+    # ... but the same NUMBERS under another provenance label are the same tables for every compatibility check:
+    # a cache built next to the datasketch package loads next to its shipped export
+    assert ht.same_tables(ht.table_id(t._replace(provenance='datasketch')), ht.table_id(t._replace(provenance='datasketch-export')))
+    assert ht.same_tables(tid, tid) and not ht.same_tables(ht.table_id(other), tid) and not ht.same_tables(None, tid)
     eh = ssa.ElphHashes(_args())
     assert eh.tables_id == tid
     eh.hll_tables = other
