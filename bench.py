@@ -28,6 +28,10 @@ roofline : the dominant kernel = ss::propagate_kernel<128,256>, the MinHash tabl
            figure is quoted under `traffic_profiled` with the file it comes from.
 step_roofline : the WHOLE step against the HBM peak: bytes of the implemented schedule / ms_per_step.
 kernels  : per kernel family, HIP-event launch durations measured on extra steps after the timed region.
+secondary : measured in the SAME process after the timed region (so the driver witnesses more than configs[1]): the ppa- and
+           citation2-like build + query steps (uniform and power-law endpoints), the ELPH call sequence at B = 2 048 and the BUDDY
+           precompute at collab size -- each with ms_per_step, the dominant kernel's fraction of the HBM peak and where its
+           table lives.  --no-secondary skips it.
 cpu_baseline : the oracle's C port (oracle/sketch_oracle.c, OpenMP on all host cores) timed on full steps of the same
            workload, rank 0 / N=1 only; `cpu_baseline_reference_style` = the reference's dataflow in stock torch CPU ops.
 """
@@ -131,6 +135,96 @@ def cpu_baseline_reference_style(ei, links, n, h, batch):
                       f'{batch}-pair query ({t_query:.3f} s); torch threads = {torch.get_num_threads()}'}
 
 
+def hub_stats(ssa, ei_np, n):
+    """(hub_edges, hub_rows) under the hub threshold a build of this graph uses: the rows the row kernels leave to the hub passes"""
+    thr = ssa.hashing.HUB_THRESHOLD if ssa.hashing.HUB_THRESHOLD is not None else ssa.hashing.default_hub_threshold(ei_np.shape[1])
+    return ssa.roofline.hub_split(np.bincount(ei_np[1], minlength=n), thr)
+
+
+def secondary_case(ssa, dev, name, config, graph='uniform', alpha=0.5, api='build_query', batch=None, steps=5, warmup=2):
+    """one more shape / call style, timed after the headline's region: the same step functions, the same fences, the dominant
+    kernel's HIP-event spans from inside the library; returns a small dict"""
+    rf, nat = ssa.roofline, ssa._native
+    lib = nat.lib()
+    cfg = CONFIGS[config]
+    n, e_und, h = cfg['n'], cfg['e_und'], cfg['h']
+    batch = batch or cfg['batch']
+    e_dir = 2 * e_und
+    eh = ssa.ElphHashes(Namespace(max_hash_hops=h, hll_p=HLL_P, minhash_num_perm=P, floor_sf=False, use_zero_one=True))
+    ei_np = synthetic_graph(n, e_und, graph, alpha)
+    n_links = min(cfg['buddy_links'], 64 * batch) if api == 'buddy' else batch
+    links = torch.from_numpy(synthetic_links(n, n_links)).to(dev)
+    ei = torch.from_numpy(ei_np).to(dev)
+    hub_e, hub_n = hub_stats(ssa, ei_np, n)
+    del ei_np
+    state = {}
+
+    def step():
+        if api == 'elph':
+            loops = torch.arange(n, device=dev).repeat(2, 1)
+            hei = torch.cat([ei, loops], dim=1)
+            if 'mh0' not in state:
+                state['mh0'], state['hll0'] = eh.initialise_minhash(n), eh.initialise_hll(n)
+            table = {0: {'minhash': state['mh0'], 'hll': state['hll0']}}
+            cards = torch.zeros((n, h), device=dev)
+            for k in range(1, h + 1):
+                table[k] = {'hll': eh.hll_prop(table[k - 1]['hll'], hei), 'minhash': eh.minhash_prop(table[k - 1]['minhash'], hei)}
+                cards[:, k - 1] = eh.hll_count(table[k]['hll'])
+            return eh.get_subgraph_features(links, table, cards)
+        table, cards = eh.build_hash_tables(n, ei)
+        return eh.get_subgraph_features(links, table, cards, batch_size=11000000)
+
+    for _ in range(warmup):
+        step()
+    # dominant kernel: the MinHash table hop, except where it does not run in full (ELPH: the query's rows only) or the link
+    # set dwarfs the build (BUDDY: the query)
+    if api == 'buddy':
+        tag, family = nat.PROF_PAIRS, 'pair_features'
+    elif api == 'elph' and ssa.hashing.DEFER_TABLE_HOP and ssa.hashing.LAZY_MINHASH and h == 2:
+        tag, family = nat.PROF_FUSED, 'fused_first_hop_hll_hop'
+    else:
+        tag, family = nat.PROF_MINHASH_HOP, 'minhash_hop'
+    lib.ss_profile_enable(1 << tag)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    dom_ms, dom_n = c_float(), c_int32()
+    lib.ss_profile_read(tag, byref(dom_ms), byref(dom_n))
+    lib.ss_profile_enable(0)
+    eh.check_errors()
+    per_launch = links.size(0) if api == 'buddy' and links.size(0) <= 11000000 else batch
+    bytes_ = rf.kernel_bytes(n, e_dir + (n if api == 'elph' else 0), P, HLL_P, h, per_launch, hub_e, hub_n)[family]
+    frac = bytes_ / (dom_ms.value * 1e-3) / 1e9 / rf.HBM_PEAK_GBS if dom_ms.value else None
+    table_bytes = rf.gathered_table_bytes(n, family, P, HLL_P, h)
+    return {'name': name, 'config': config, 'graph': graph if graph == 'uniform' else f'{graph} (endpoint weights ~ rank^-{alpha})',
+            'api': api, 'num_nodes': n, 'directed_edges': e_dir, 'max_hash_hops': h, 'pairs_per_step': links.size(0),
+            'ms_per_step': ms, 'pairs_per_s': links.size(0) / (ms * 1e-3), 'steps': steps,
+            'dominant_kernel': family, 'dominant_mean_launch_ms': dom_ms.value, 'dominant_launches': dom_n.value,
+            'dominant_algorithmic_bytes': bytes_, 'dominant_frac_of_hbm_peak': frac,
+            'hub_rows': hub_n, 'hub_edge_share': hub_e / e_dir,
+            'resident': 'infinity-cache' if table_bytes <= rf.INFINITY_CACHE_BYTES else 'hbm',
+            'cache_resident_fraction': rf.cache_resident_fraction(table_bytes),
+            **({'note': 'above 1: algorithmic bytes count one row read per in-edge; on this skewed graph the sources of the regular '
+                        'rows\' in-edges repeat (endpoint weights ~ rank^-alpha) and a cache-resident table serves the repeats from '
+                        'the L2 / Infinity Cache -- more bytes reach the CUs than HBM could deliver, none are skipped (every row '
+                        'is checked against the oracle in tests/test_gpu_parity.py::test_full_size_configs_vs_oracle)'}
+               if frac and frac > 1.0 else {})}
+
+
+SECONDARY = [
+    # (name, config, graph, alpha, api, batch): BASELINE configs[3] / [4] as SURVEY 8(d) asks -- U and PL at the same N, E --,
+    # configs[2] (the ELPH message-passing step at the reference's batch size), BUDDY's precompute at collab size
+    ('ppa_uniform', 'ppa', 'uniform', 0.5, 'build_query', None), ('ppa_powerlaw', 'ppa', 'powerlaw', 0.5, 'build_query', None),
+    ('citation2_uniform', 'citation2', 'uniform', 0.5, 'build_query', None),
+    ('citation2_powerlaw', 'citation2', 'powerlaw', 0.5, 'build_query', None),
+    ('collab_powerlaw09', 'collab', 'powerlaw', 0.9, 'build_query', None),
+    ('collab_elph_b2048', 'collab', 'uniform', 0.5, 'elph', 2048), ('collab_buddy', 'collab', 'uniform', 0.5, 'buddy', None),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -156,7 +250,9 @@ def main():
     ap.add_argument('--build', default='replicated', choices=['replicated', 'sharded'],
                     help='N > 1 only. replicated (default): every rank builds the whole table; sharded: destination rows split '
                          'across ranks + in-place all-gather after every hop (pays off at ogbl-ppa / citation2 sizes)')
-    ap.add_argument('--sustain-seconds', type=float, default=1.0, help='length of the sustained run after the timed region (0 = skip)')
+    ap.add_argument('--sustain-seconds', type=float, default=8.0,
+                    help='length of the sustained run after the timed region (0 = skip); long enough for a 5 s utilisation sampler')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` shapes measured after the timed region')
     ap.add_argument('--no-kernel-table', action='store_true', help='skip the per-kernel HIP-event table (extra steps after the timed region)')
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -192,6 +288,7 @@ def main():
     pairs_planned = batch * buddy_batches if a.api == 'buddy' else batch
     plan = ssa.dist.BatchPlan(a.scaling, world, rank, pairs_planned)
     ei_np = synthetic_graph(n, e_und, a.graph, a.alpha)
+    hub_e, hub_n = hub_stats(ssa, ei_np, n)  # rows (and their in-edges) the row kernels leave to the hub passes
     links_np = synthetic_links(n, pairs_planned, plan.links_seed)
     ei = torch.from_numpy(ei_np).to(dev)
     links = plan.local(torch.from_numpy(links_np).to(dev)).contiguous()
@@ -305,7 +402,8 @@ def main():
             step()
         fence()
         lib.ss_profile_enable(0)
-        model = rf.kernel_bytes(n, e_dir, P, HLL_P, h, min(links.size(0), batch))
+        model = rf.kernel_bytes(n, e_dir, P, HLL_P, h, min(links.size(0), batch), hub_e, hub_n)
+        model['hub_passes'] = (model['hub_first_hop'] + (h - 1) * model['hub_table_hop']) // h  # mean over the h launches of a step
         model['minhash_hop_rows'] = rf.minhash_rows_bytes(n, e_dir, 2 * min(links.size(0), batch), P)
         kernel_table = {}
         for name, tag in tags.items():
@@ -322,10 +420,10 @@ def main():
                                 'spans all launches of one build; hub_passes = the hub / mega-row launches of every hop')
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------------------------
-    prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch)['minhash_hop']
+    prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch, hub_e, hub_n)['minhash_hop']
     roof_kernel = "ss::propagate_kernel<128,256> (MinHash table hop: (E'+N)*4P + 4E + 8(N+1) bytes)"
     if dom_tag == nat.PROF_FUSED:
-        prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch)['fused_first_hop_hll_hop']
+        prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch, hub_e, hub_n)['fused_first_hop_hll_hop']
         roof_kernel = ("ss::fused_hop_persistent_kernel<2> (MinHash first hop + HLL table hop: 4E + 8(N+1) + N*4P + (E'+N)*M + 4N bytes; "
                        "VALU-bound first hop over the memory-bound table hop)")
     if sharded_build:  # each launch covers this rank's N/G destination rows and (on the uniform graph) E'/G in-edges
@@ -342,7 +440,7 @@ def main():
                     'collected': blob.get('collected', 'separate rocprofv3 --pmc passes of this command (tools/prof.sh), not this run'),
                     'note': 'FETCH_SIZE counts fabric requests including Infinity-Cache hits: it shows the absence of L2 re-reads, '
                             'it is not an HBM byte count'}
-    step_bytes = rf.step_bytes_implemented(n, e_dir, P, HLL_P, h, links.size(0))
+    step_bytes = rf.step_bytes_implemented(n, e_dir, P, HLL_P, h, links.size(0), hub_e, hub_n)
     step_ok = a.api == 'build_query' and not sharded_build
     out = {
         'metric': 'edge-pairs/sec subgraph-feature extraction (build+query)',
@@ -350,7 +448,9 @@ def main():
         'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': a.scaling,
         'vs_baseline': None, 'dtype': 'u32/u8 sketches, f32 estimator', 'data': 'synthetic',
         'config': {'workload': f'ogbl-{a.config}-like synthetic {a.graph} graph' + (' (BASELINE configs[1])' if a.config == 'collab' else '') +
-                               ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps' +
+                               ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps; '
+                               'tables stay in the packed u32 / u8 layout the query reads -- the reference-shaped int64 [N, P] views of '
+                               'the returned dict are lazy and are NOT materialised inside a step' +
                                ('' if a.api == 'build_query' else f' [api mode: {a.api}' + (f', {pairs_planned} links per build, get_subgraph_features in chunks of {a.buddy_chunk} (datasets/elph.py:207-208)' if a.api == 'buddy' else '')
                                 + (', last-hop MinHash rows computed for the queried nodes only (hashing.DEFER_TABLE_HOP; SS_DEFER_TABLE_HOP=0: all N rows)'
                                    if a.api == 'elph' and ssa.hashing.DEFER_TABLE_HOP else '') + ']'),
@@ -366,6 +466,9 @@ def main():
                      'frac': achieved / rf.HBM_PEAK_GBS if achieved else None, 'traffic': None, 'traffic_profiled': profiled,
                      'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n,
                      'resident': rf.residency(n, 'hll_hop' if dom_tag == nat.PROF_FUSED else 'minhash_hop', P, HLL_P),
+                     'cache_resident_fraction': rf.cache_resident_fraction(rf.gathered_table_bytes(
+                         n, 'hll_hop' if dom_tag == nat.PROF_FUSED else 'minhash_hop', P, HLL_P, h)),
+                     'hub_rows': hub_n, 'hub_edge_share': hub_e / e_dir,
                      'unique_hbm_bytes_per_launch': (rf.unique_bytes(n, e_dir, 'hll_hop', P, HLL_P) + n * 4 * P if dom_tag == nat.PROF_FUSED else
                                                      rf.unique_bytes(n, e_dir, 'minhash_hop', P, HLL_P) // (world if sharded_build else 1)),
                      'note': 'resident = infinity-cache: the gathered table (N*4P bytes) fits the 256 MiB Infinity Cache, so `achieved` is a '
@@ -394,10 +497,26 @@ def main():
                                      if world > 1 else 'single GPU: nothing is repeated')
     if kernel_table:
         out['kernels'] = kernel_table
+    default_line = a.config == 'collab' and a.graph == 'uniform' and a.api == 'build_query' and batch == cfg['batch']
+    feats_host = feats.cpu().numpy() if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
+    if rank == 0 and world == 1 and not a.no_secondary and default_line:
+        ei = links = feats = None  # (the headline's device tensors make room for the larger shapes)
+        torch.cuda.empty_cache()
+        out['secondary'] = {}
+        for name, config, graph, alpha, api, b in SECONDARY:
+            try:
+                out['secondary'][name] = secondary_case(ssa, dev, name, config, graph, alpha, api, b)
+            except Exception as exc:  # a secondary shape must never cost the headline line
+                out['secondary'][name] = {'error': f'{type(exc).__name__}: {exc}'}
+            torch.cuda.empty_cache()
+        out['secondary']['note'] = ('same process, after the timed region and the sustained run: build + query steps of the other BASELINE '
+                                    'shapes (uniform and power-law endpoints at the same N, E), the ELPH call sequence at the reference batch, '
+                                    'the BUDDY precompute; dominant_frac_of_hbm_peak = algorithmic bytes of the dominant kernel (hub rows '
+                                    'excluded from the row kernels\' bytes) / its mean HIP-event span / 8 TB/s')
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config in ('collab', 'cora') and a.api == 'build_query' and batch == cfg['batch']:
         base, ofeat = cpu_baseline(ei_np, links_np, n, h, batch)
         out['cpu_baseline'] = base
-        out['cpu_baseline']['max_abs_feature_diff_vs_gpu'] = float(np.abs(feats.cpu().numpy() - ofeat).max())
+        out['cpu_baseline']['max_abs_feature_diff_vs_gpu'] = float(np.abs(feats_host - ofeat).max())
         out['speedup_vs_cpu_baseline'] = out['value'] / base['value']
         if a.config == 'collab':
             out['cpu_baseline_reference_style'] = cpu_baseline_reference_style(ei_np, links_np, n, h, batch)

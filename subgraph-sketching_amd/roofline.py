@@ -25,21 +25,37 @@ def graph_read_bytes(N, E):
     return 4 * E + 8 * (N + 1)
 
 
-def kernel_bytes(N, E, P=128, p=8, h=2, B=65536):
-    """algorithmic bytes per LAUNCH of each kernel family of one step (build_hash_tables + one query batch)"""
-    M, Ep = 1 << p, E + N
+def kernel_bytes(N, E, P=128, p=8, h=2, B=65536, hub_edges=0, hub_rows=0):
+    """algorithmic bytes per LAUNCH of each kernel family of one step (build_hash_tables + one query batch).
+    hub_edges / hub_rows: in-edges and count of the rows above the hub threshold.  The row kernels SKIP those rows and the
+    hub passes walk them, so their bytes belong to `hub_first_hop` / `hub_table_hop` (one launch per hop, both sketches), not to
+    the row kernels: crediting them to `minhash_hop` gave a roofline fraction above 1 on skewed graphs (VERDICT r2 weak #3)."""
+    M = 1 << p
+    R = 4 * P + M
+    Er, Nr = E - hub_edges, N - hub_rows      # what the row kernels walk / write
+    Epr = Er + Nr                              # + one implicit self loop per written row
+    graph = 4 * Er + 8 * (N + 1)               # col entries of the walked rows + rowptr
     return {
         'csr_build': csr_bytes(N, E),
         # hop 1 from node ids: no table reads (hop-0 rows are recomputed in registers)
-        'first_hop_hll': graph_read_bytes(N, E) + N * M + 4 * N,            # writes the HLL rows + cards[:, 0]
-        'first_hop_minhash': graph_read_bytes(N, E) + N * 4 * P,            # writes the MinHash rows
+        'first_hop_hll': graph + Nr * M + 4 * Nr,                          # writes the HLL rows + cards[:, 0]
+        'first_hop_minhash': graph + Nr * 4 * P,                           # writes the MinHash rows
         # table hops (k = 2..h): one input row per edge and self loop, one output row per node
-        'hll_hop': (Ep + N) * M + graph_read_bytes(N, E) + 4 * N,           # + cards[:, k-1]
-        'minhash_hop': (Ep + N) * 4 * P + graph_read_bytes(N, E),
+        'hll_hop': (Epr + Nr) * M + graph + 4 * Nr,                        # + cards[:, k-1]
+        'minhash_hop': (Epr + Nr) * 4 * P + graph,
         'pair_features': B * pair_bytes(P, p, h),
         # ss_fused_hop_stage's kernel: MinHash first hop + HLL table hop of hop 2 in one launch (the CSR is read once)
-        'fused_first_hop_hll_hop': graph_read_bytes(N, E) + N * 4 * P + (Ep + N) * M + 4 * N,
+        'fused_first_hop_hll_hop': graph + Nr * 4 * P + (Epr + Nr) * M + 4 * Nr,
+        # hub passes: both sketches of the hub / mega rows of one hop (col + two rowptr words + list entry per row)
+        'hub_first_hop': 4 * hub_edges + 20 * hub_rows + hub_rows * R + 4 * hub_rows,
+        'hub_table_hop': (hub_edges + 2 * hub_rows) * R + 4 * hub_edges + 20 * hub_rows + 4 * hub_rows,
     }
+
+
+def hub_split(in_degree, hub_threshold):
+    """(hub_edges, hub_rows) of a graph from its in-degree array (numpy) -- the arguments kernel_bytes takes"""
+    hub = in_degree > hub_threshold
+    return int(in_degree[hub].sum()), int(hub.sum())
 
 
 def minhash_rows_bytes(N, E, n_rows, P=128):
@@ -53,11 +69,12 @@ def pair_bytes(P=128, p=8, h=2):
     return 2 * h * (4 * P + (1 << p)) + 16 + 8 * h + 4 * h * (h + 2)
 
 
-def step_bytes_implemented(N, E, P=128, p=8, h=2, B=65536):
-    """bytes of one step under the implemented schedule: CSR build, hop 1 from node ids, h - 1 table hops, one query batch"""
-    k = kernel_bytes(N, E, P, p, h, B)
-    return (k['csr_build'] + k['first_hop_hll'] + k['first_hop_minhash'] + (h - 1) * (k['hll_hop'] + k['minhash_hop'])
-            + k['pair_features'])
+def step_bytes_implemented(N, E, P=128, p=8, h=2, B=65536, hub_edges=0, hub_rows=0):
+    """bytes of one step under the implemented schedule: CSR build, hop 1 from node ids, h - 1 table hops, one query batch
+    (the hub passes included: the same rows and edges, walked by other launches)"""
+    k = kernel_bytes(N, E, P, p, h, B, hub_edges, hub_rows)
+    return (k['csr_build'] + k['first_hop_hll'] + k['first_hop_minhash'] + k['hub_first_hop']
+            + (h - 1) * (k['hll_hop'] + k['minhash_hop'] + k['hub_table_hop']) + k['pair_features'])
 
 
 def step_bytes_survey(N, E, P=128, p=8, h=2, B=65536):
@@ -78,6 +95,18 @@ def unique_bytes(N, E, family, P=128, p=8):
 
 def residency(N, family, P=128, p=8):
     """'infinity-cache' when the table a hop gathers from fits the 256 MiB Infinity Cache (its random row reads are then
-    mostly served there and `achieved` can exceed what HBM alone streams), else 'hbm'"""
+    mostly served there and `achieved` can exceed what HBM alone streams), else 'hbm'.  The label is a threshold;
+    `cache_resident_fraction` is the number to read (a 295 MB table is 'hbm' and still 91 % cache-resident)."""
     row = {'minhash_hop': 4 * P, 'hll_hop': 1 << p}[family]
     return 'infinity-cache' if N * row <= INFINITY_CACHE_BYTES else 'hbm'
+
+
+def cache_resident_fraction(table_bytes):
+    """share of a gathered table set the 256 MiB Infinity Cache can hold: min(1, 256 MiB / bytes) (VERDICT r2 weak #4)"""
+    return 1.0 if table_bytes <= 0 else min(1.0, INFINITY_CACHE_BYTES / float(table_bytes))
+
+
+def gathered_table_bytes(N, family, P=128, p=8, h=2):
+    """bytes of the table(s) a kernel family gathers rows from"""
+    M = 1 << p
+    return {'minhash_hop': N * 4 * P, 'hll_hop': N * M, 'fused_first_hop_hll_hop': N * M, 'pair_features': h * N * (4 * P + M)}[family]

@@ -268,6 +268,28 @@ def test_byte_model_of_the_step(ssa):
     # listed row), over one ELPH batch 1.7 % of it
     assert abs(rf.minhash_rows_bytes(n, e, n) - (k['minhash_hop'] + 16 * n)) < 1e5
     assert abs(rf.minhash_rows_bytes(n, e, 4096) / k['minhash_hop'] - 4096 / n) < 1e-3
+    # skewed graphs: the rows above the hub threshold are walked by the hub passes -- their bytes are NOT the row kernels'
+    # (a fraction of 1.305 came from crediting them to propagate_kernel); nothing is lost or counted twice
+    import numpy as np
+    deg = np.full(n, 10, dtype=np.int64)
+    deg[:50] = 20000
+    eh_, nh_ = rf.hub_split(deg, 144)
+    assert (eh_, nh_) == (50 * 20000, 50)
+    e2 = int(deg.sum())
+    ks = rf.kernel_bytes(n, e2, 128, 8, 2, 65536, eh_, nh_)
+    k0 = rf.kernel_bytes(n, e2, 128, 8, 2, 65536)
+    assert ks['minhash_hop'] == (e2 - eh_ + 2 * (n - nh_)) * 512 + 4 * (e2 - eh_) + 8 * (n + 1) < k0['minhash_hop']
+    assert k0['hub_table_hop'] == 0 and k0['hub_first_hop'] == 0
+    assert ks['hub_table_hop'] == (eh_ + 2 * nh_) * 768 + 4 * eh_ + 24 * nh_
+    moved = (k0['minhash_hop'] + k0['hll_hop']) - (ks['minhash_hop'] + ks['hll_hop'])
+    # (one hub pass serves both sketches: it reads the rows' col entries once where the two row kernels read them twice; per row
+    # it also reads its list entry and both rowptr words)
+    assert abs(moved - 4 * eh_ - ks['hub_table_hop']) <= 32 * nh_
+    assert abs(rf.step_bytes_implemented(n, e2, 128, 8, 2, 65536, eh_, nh_) + 8 * eh_ - rf.step_bytes_implemented(n, e2, 128, 8, 2, 65536)) <= 64 * nh_
+    # residency as a fraction: the label is a threshold, the number is what to read
+    assert rf.cache_resident_fraction(rf.gathered_table_bytes(n, 'minhash_hop')) == 1.0
+    assert abs(rf.cache_resident_fraction(rf.gathered_table_bytes(576289, 'minhash_hop')) - 0.9097) < 1e-3
+    assert abs(rf.cache_resident_fraction(rf.gathered_table_bytes(2927963, 'pair_features', h=3)) - 0.0398) < 1e-3
 
 
 def test_batch_plan_bookkeeping(ssa):

@@ -3,7 +3,7 @@
    profiles/<tag>_kernel_stats.csv  (rocprofv3 --kernel-trace --stats: average duration per kernel)
    profiles/<tag>_pmc.json          (separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB per dispatch)
    subgraph-sketching_amd/roofline.py (algorithmic bytes per launch)
-usage: python tools/roofline_table.py <tag> <config> [--graph powerlaw]     -> profiles/<tag>_roofline.md
+usage: python tools/roofline_table.py <tag> <config> [--graph powerlaw --alpha a]     -> profiles/<tag>_roofline.md
 HBM bytes from PMC = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE tallies the 128-B requests of dwordx4 streams
 at 64 B, MI355X_MICROARCH.md "HBM"); the counters sit on the fabric side of the L2 and INCLUDE Infinity-Cache hits, so for a
 table that fits the 256 MiB cache they show "no L2 re-reads", not HBM bytes -- the `resident` column says which case applies."""
@@ -17,7 +17,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (CONFIGS only)
 import subgraph_sketching_amd as ssa  # noqa: E402
 
-FAMILIES = [('propagate_kernel<128, 256>', 'minhash_hop'), ('hll_propagate_row16_kernel', 'hll_hop'),
+FAMILIES = [('propagate_hub_kernel', 'hub_table_hop'), ('first_hop_hub_kernel', 'hub_first_hop'),
+            ('propagate_kernel<128, 256>', 'minhash_hop'), ('hll_propagate_row16_kernel', 'hll_hop'),
             ('first_hop_kernel<2, true, false>', 'first_hop_minhash'), ('first_hop_rows_kernel<2', 'first_hop_minhash'),
             ('hll_first_hop_kernel', 'first_hop_hll'), ('fused_hop_persistent_kernel', 'fused_first_hop_hll_hop'),
             ('pair_features_kernel', 'pair_features')]
@@ -28,7 +29,13 @@ def main():
     cfg = bench.CONFIGS[config]
     n, e, h, b = cfg['n'], 2 * cfg['e_und'], cfg['h'], cfg['batch']
     rf = ssa.roofline
-    model = rf.kernel_bytes(n, e, 128, 8, h, b)
+    hub_e = hub_n = 0
+    if '--graph' in sys.argv:  # skewed shapes: the rows above the hub threshold belong to the hub passes, not to the row kernels
+        import numpy as np
+        kind = sys.argv[sys.argv.index('--graph') + 1]
+        alpha = float(sys.argv[sys.argv.index('--alpha') + 1]) if '--alpha' in sys.argv else 0.5
+        hub_e, hub_n = bench.hub_stats(ssa, bench.synthetic_graph(n, cfg['e_und'], kind, alpha), n)
+    model = rf.kernel_bytes(n, e, 128, 8, h, b, hub_e, hub_n)
     stats = {r['Name']: r for r in csv.DictReader(l for l in open(os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats.csv')) if not l.startswith('#'))}
     pmc_path = os.path.join(ROOT, 'profiles', f'{tag}_pmc.json')
     pmc = json.load(open(pmc_path))['raw'] if os.path.exists(pmc_path) else {}
@@ -57,9 +64,9 @@ def main():
     calls = max(int(r['Calls']) for nme, r in stats.items() if 'propagate_kernel<128' in nme) // max(h - 1, 1)
     step_us = ours_ns / 1e3 / calls
     lines += ['', f'Sum of the engine\'s kernels per step (kernel time only, {calls} steps traced): **{step_us:.1f} us**; bytes of the implemented '
-                  f'schedule per step {rf.step_bytes_implemented(n, e, 128, 8, h, b) / 1e9:.3f} GB '
-                  f'-> {rf.step_bytes_implemented(n, e, 128, 8, h, b) / step_us / 1e3:.0f} GB/s = '
-                  f'{rf.step_bytes_implemented(n, e, 128, 8, h, b) / step_us / 1e3 / rf.HBM_PEAK_GBS:.3f} of peak over kernel time.']
+                  f'schedule per step {rf.step_bytes_implemented(n, e, 128, 8, h, b, hub_e, hub_n) / 1e9:.3f} GB '
+                  f'-> {rf.step_bytes_implemented(n, e, 128, 8, h, b, hub_e, hub_n) / step_us / 1e3:.0f} GB/s = '
+                  f'{rf.step_bytes_implemented(n, e, 128, 8, h, b, hub_e, hub_n) / step_us / 1e3 / rf.HBM_PEAK_GBS:.3f} of peak over kernel time.']
     out = os.path.join(ROOT, 'profiles', f'{tag}_roofline.md')
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
