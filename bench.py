@@ -244,6 +244,9 @@ def main():
                          'runners/run.py:238)')
     ap.add_argument('--buddy-links', type=int, default=None,
                     help='pairs per BUDDY precompute (default: min(the config\'s L, 64 batches)); a step = the build + all of them')
+    ap.add_argument('--buddy-negs', type=int, default=0,
+                    help='--api buddy: link set in evaluation style -- this many pairs per source node, listed together (ogbl-citation2: '
+                         '1 000 negatives per source); 0 (default) = pairs drawn uniformly at random')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='N > 1. weak (default): every rank its own batch, replicated build (N x by construction); strong: one '
                          'global batch / link set sharded across the ranks (BASELINE configs[3], [4])')
@@ -290,6 +293,8 @@ def main():
     ei_np = synthetic_graph(n, e_und, a.graph, a.alpha)
     hub_e, hub_n = hub_stats(ssa, ei_np, n)  # rows (and their in-edges) the row kernels leave to the hub passes
     links_np = synthetic_links(n, pairs_planned, plan.links_seed)
+    if a.api == 'buddy' and a.buddy_negs > 0:  # every source's pairs listed together
+        links_np[:, 0] = np.repeat(links_np[::a.buddy_negs, 0], a.buddy_negs)[:pairs_planned]
     ei = torch.from_numpy(ei_np).to(dev)
     links = plan.local(torch.from_numpy(links_np).to(dev)).contiguous()
     gather = ssa.dist.AsyncFeatureGather(plan, nf, dev) if launched else (lambda f: f)
@@ -451,7 +456,7 @@ def main():
                                ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps; '
                                'tables stay in the packed u32 / u8 layout the query reads -- the reference-shaped int64 [N, P] views of '
                                'the returned dict are lazy and are NOT materialised inside a step' +
-                               ('' if a.api == 'build_query' else f' [api mode: {a.api}' + (f', {pairs_planned} links per build, get_subgraph_features in chunks of {a.buddy_chunk} (datasets/elph.py:207-208)' if a.api == 'buddy' else '')
+                               ('' if a.api == 'build_query' else f' [api mode: {a.api}' + (f', {pairs_planned} links per build' + (f' ({a.buddy_negs} per source, listed together)' if a.buddy_negs else ' (uniformly random pairs)') + f', get_subgraph_features in chunks of {a.buddy_chunk} (datasets/elph.py:207-208); link sets >= {ssa.hashing.GROUP_LINKS_MIN} pairs are grouped by their first node unless they already are (hashing.GROUP_LINKS_MIN)' if a.api == 'buddy' else '')
                                 + (', last-hop MinHash rows computed for the queried nodes only (hashing.DEFER_TABLE_HOP; SS_DEFER_TABLE_HOP=0: all N rows)'
                                    if a.api == 'elph' and ssa.hashing.DEFER_TABLE_HOP else '') + ']'),
                    'num_nodes': n, 'directed_edges': e_dir, 'max_hash_hops': h, 'minhash_num_perm': P, 'hll_p': HLL_P,

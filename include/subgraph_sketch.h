@@ -191,6 +191,29 @@ int ss_pair_features_normalised(const int64_t *links, int64_t B, int64_t N, int3
                                 const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
                                 const float *degrees, float *out, int32_t *err_flag, void *stream);
 
+/* The query exploiting LINK LOCALITY (BUDDY's precompute IS the query at ogbl-ppa / citation2 scale: datasets/elph.py:207-208
+ * hands get_subgraph_features every link of a split; hashing.py:270-274, :180-183 read the rows of u and v once per pair, yet
+ * the link sets repeat every source many times -- ogbl-citation2's evaluation set lists 1 000 negatives per source).
+ *   ss_group_links_by_source: order[0 .. B) := a permutation of the pair indices in which all pairs with the same first node
+ *     are consecutive (torch-style negative ids wrapped; ids out of range are keyed to node 0 -- nothing is dropped, the query
+ *     reports them).  rowptr: int64[N + 1] scratch output (start of every node's group).  Workspace:
+ *     ss_csr_workspace_bytes(N, B).  B < 2^31.
+ *   ss_pair_features_grouped: ss_pair_features / ss_pair_features_normalised (degrees non-null) walking the pairs in the order
+ *     given (order == NULL: as listed) and re-reading the rows of a first node only when it changes.  Row q of `out` is pair
+ *     q; rows are bit-identical to the ungrouped entry points' (a pair's features depend on its own rows only). */
+int ss_group_links_by_source(const int64_t *links, int64_t B, int64_t N, int32_t *order, int64_t *rowptr, void *workspace,
+                             size_t workspace_bytes, void *stream);
+/* The two permutations around a grouped query over a link set of gigabytes (the features of ogbl-citation2's 356 M links are
+ * 21 GB): out_links[t] := links[order[t]] (int64 [n, 2]) before, out[order[t], :] := rows[t, :] (float [n, width]) after a
+ * ss_pair_features_grouped(order = NULL) over the gathered chunk -- walking `order` inside the query would make every pair
+ * read and write at random places of those arrays from inside its latency chain. */
+int ss_gather_links(const int64_t *links, const int32_t *order, int64_t n, int64_t *out_links, void *stream);
+int ss_scatter_feature_rows(const float *rows, const int32_t *order, int64_t n, int32_t width, float *out, void *stream);
+int ss_pair_features_grouped(const int64_t *links, const int32_t *order, int64_t B, int64_t N, int32_t h,
+                             const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
+                             const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
+                             const float *degrees, float *out, int32_t *err_flag, void *stream);
+
 /* Weighted common-neighbour scores of node pairs -- the other per-link precompute of HashDataset.__init__ (SURVEY 8(f)
  * row N4; reference datasets/elph.py:76-77,314 calling heuristics.py:51-70 RA; CN heuristics.py:10-27 and AA :30-48
  * are the same sum with another multiplier):

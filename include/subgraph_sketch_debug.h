@@ -45,6 +45,13 @@ int ss_time_pair_features(const int64_t *links, int64_t B, int64_t N, int32_t h,
                           const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
                           float *out, void *stream, int32_t reps, float *ms_out);
 
+/* ss_pair_features_grouped with its kernel forced (which = 0: the ordinary kernel walking `order`, 1: the run-aware kernel);
+ * the product entry point chooses per hop count.  For tools/probe_pair_runs.py and the parity test of both kernels. */
+int ss_pair_features_grouped_kernel(int32_t which, const int64_t *links, const int32_t *order, int64_t B, int64_t N, int32_t h,
+                                    const uint32_t *const *mh, int32_t P, const uint8_t *const *hll,
+                                    const float *cards, int64_t cards_stride, const ss_hll_params *prm, uint32_t flags,
+                                    const float *degrees, float *out, int32_t *err_flag, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,14 @@ SIGNATURES = {
     'ss_pair_features_normalised': (c_int32, [c_void_p, c_int64, c_int64, c_int32, POINTER(c_void_p), c_int32,
                                               POINTER(c_void_p), c_void_p, c_int64, POINTER(HllParams), c_uint32, c_void_p,
                                               c_void_p, c_void_p, c_void_p]),
+    'ss_group_links_by_source': (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ss_gather_links': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    'ss_scatter_feature_rows': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    'ss_pair_features_grouped': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, POINTER(c_void_p), c_int32, POINTER(c_void_p),
+                                           c_void_p, c_int64, POINTER(HllParams), c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ss_pair_features_grouped_kernel': (c_int32, [c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, POINTER(c_void_p), c_int32,
+                                                  POINTER(c_void_p), c_void_p, c_int64, POINTER(HllParams), c_uint32, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p]),
     'ss_common_neighbour_scores': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                              c_void_p]),
     'ss_spmm_csr': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),

@@ -224,9 +224,27 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_keys(uint32_t x /* 0 fo
     return pre + inc - x;
 }
 
+// Entry e of the caller's list as (source, destination).  Edge lists: src[e], dst[e].  LINK lists (ss_group_links_by_source:
+// the pairs of a query grouped by their first node): src == nullptr, dst = links [B, 2] -- the key is the pair's first node,
+// torch-style negative ids wrapped, ids out of range keyed to node 0 (the query kernel itself reports them and writes their NaN
+// rows: nothing may be dropped here), and the "source" is the pair's index.
+__device__ __forceinline__ void fetch_edge(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t e, int64_t N, int64_t &s,
+                                           int64_t &d)
+{
+    if (src) {
+        s = src[e];
+        d = dst[e];
+    } else {
+        int64_t u = dst[2 * e];
+        u = u < 0 ? u + N : u;
+        d = (uint64_t)u < (uint64_t)N ? u : 0;
+        s = e;
+    }
+}
+
 // where a workgroup's edges come from and how they are keyed
 struct PassArgs {
-    const int64_t *src, *dst;            // pass 1 input: slices of the caller's edge list
+    const int64_t *src, *dst;            // pass 1 input: slices of the caller's edge list (src == nullptr: a link list, see fetch_edge)
     const int2 *staged;                  // pass 2 input: parts of one pass-1 bucket
     const unsigned long long *seg_base;  // pass 2: base1[keys1 + 1]
     int64_t E, N, slice;                 // pass 1
@@ -286,7 +304,15 @@ __global__ __launch_bounds__(kThreads) void count_keys_kernel(PassArgs a, uint32
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t e = e0 + threadIdx.x + (int64_t)k * kThreads;
-            d[k] = e < hi ? (PASS2 ? (int64_t)a.staged[e].y : a.dst[e]) : (int64_t)-1;
+            d[k] = -1;
+            if (e < hi) {
+                if (PASS2) {
+                    d[k] = (int64_t)a.staged[e].y;
+                } else {
+                    int64_t s_unused;
+                    fetch_edge(a.src, a.dst, e, a.N, s_unused, d[k]);
+                }
+            }
             if (!PASS2 && e < hi && (uint64_t)d[k] >= (uint64_t)a.N) {  // out of range: dropped (and reported)
                 bad = true;
                 d[k] = -1;
@@ -416,12 +442,11 @@ __global__ __launch_bounds__(kScatterThreads) void scatter_tiles_kernel(PassArgs
                     s = v.x;
                     d = v.y;
                 } else {
-                    s = a.src[e];
-                    d = a.dst[e];
+                    fetch_edge(a.src, a.dst, e, a.N, s, d);
                     const int64_t mx = s > d ? s : d;
                     my_max = mx > my_max ? mx : my_max;
                     if ((uint64_t)d >= (uint64_t)a.N) continue;               // dropped, exactly as count_keys did
-                    if ((uint64_t)s >= (uint64_t)a.N) { bad = true; s = 0; }  // memory safe; the host raises in strict mode
+                    if (a.src && (uint64_t)s >= (uint64_t)a.N) { bad = true; s = 0; }  // memory safe; the host raises in strict mode
                 }
                 ed[k] = make_int2((int)s, (int)d);
                 key[k] = key_of<PASS2>(a, d, group);
@@ -722,12 +747,12 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
         key[k] = -1;
         ed[k] = make_int2(0, 0);
         if (e < hi) {
-            int64_t s = src[e];
-            const int64_t d = dst[e];
+            int64_t s, d;
+            fetch_edge(src, dst, e, N, s, d);
             const int64_t mx = s > d ? s : d;
             my_max = mx > my_max ? mx : my_max;
             if ((uint64_t)d >= (uint64_t)N) { bad = true; continue; }    // out of range: dropped (and reported)
-            if ((uint64_t)s >= (uint64_t)N) { bad = true; s = 0; }       // memory safe; the host raises in strict mode
+            if (src && (uint64_t)s >= (uint64_t)N) { bad = true; s = 0; }  // memory safe; the host raises in strict mode
             ed[k] = make_int2((int)s, (int)d);
             key[k] = (int)(d >> shift);
         }
@@ -1117,14 +1142,43 @@ extern "C" size_t ss_csr_workspace_bytes(int64_t N, int64_t E)
     return ss::carve(p, E, nullptr).bytes;
 }
 
+static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
+                          int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
+                          int32_t *mega_rows, int32_t *mega_count,
+                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_);
+
 extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                             int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
                             int32_t *mega_rows, int32_t *mega_count,
                             int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_)
 {
+    if (E > 0 && !src) return SS_ERR_INVALID_ARG;
+    return csr_build_impl(src, dst, E, N, rowptr, col, n_self_loops_out, hub_threshold, hub_rows, hub_count, mega_rows, mega_count, err_flag,
+                          workspace, workspace_bytes, stream_);
+}
+
+// The pairs of a query grouped by their first node (reference hashing.py:270-274 reads cards[u] / the rows of u once per PAIR;
+// BUDDY's link sets repeat every source many times -- ogbl-citation2's evaluation set lists 1 000 negatives per source): the
+// CSR builder run on (destination = first node of pair q, source = q).  order[0 .. B) is a permutation of the pair indices in
+// which all pairs of one first node are consecutive (rowptr [N + 1] says where each node's group starts).  Nothing is dropped:
+// ids out of range are keyed to node 0.  ss_pair_features_grouped walks `order` and reloads a first node's rows only when it
+// changes.  Workspace: ss_csr_workspace_bytes(N, B).
+extern "C" int ss_group_links_by_source(const int64_t *links, int64_t B, int64_t N, int32_t *order, int64_t *rowptr, void *workspace,
+                                        size_t workspace_bytes, void *stream)
+{
+    if (B < 0 || B >= ((int64_t)1 << 31) || N <= 0 || (B > 0 && (!links || !order))) return SS_ERR_INVALID_ARG;
+    return csr_build_impl(nullptr, links, B, N, rowptr, order, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
+                          workspace_bytes, stream);
+}
+
+static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
+                          int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
+                          int32_t *mega_rows, int32_t *mega_count,
+                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_)
+{
     using namespace ss;
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || !rowptr) return SS_ERR_INVALID_ARG;
-    if (E > 0 && (!src || !dst || !col)) return SS_ERR_INVALID_ARG;
+    if (E > 0 && (!dst || !col)) return SS_ERR_INVALID_ARG;
     if ((hub_rows == nullptr) != (hub_count == nullptr)) return SS_ERR_INVALID_ARG;
     if ((mega_rows == nullptr) != (mega_count == nullptr) || (mega_rows && !hub_rows)) return SS_ERR_INVALID_ARG;
     CsrPlan p;

@@ -14,6 +14,7 @@
 // runs the HLL++ estimator for combination c and the h(h+2) features are assembled in fp32 in the
 // reference's own operation order.
 #include <cstdlib>
+#include <cstring>
 
 #include "ss_common.hpp"
 
@@ -134,8 +135,10 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
                                                             ss_hll_params prm, uint32_t flags, float *__restrict__ out,
                                                             int32_t *__restrict__ dbg_match, int32_t *__restrict__ dbg_zero,
                                                             float *__restrict__ dbg_inter, int32_t *__restrict__ err,
-                                                            const float *__restrict__ degrees)
+                                                            const float *__restrict__ degrees, const int32_t *__restrict__ order)
 {
+    // order (nullable): position t of the walk is pair order[t] (ss_pair_features_grouped: pairs with the same first node are
+    // consecutive positions, i.e. neighbouring lane groups of one workgroup -- their rows of u meet in the CU's L1 / the L2)
     __shared__ EstimatorLds lds;
     // the estimator tables are staged into LDS AFTER the first pair's sketch rows have been requested (first loop iteration
     // below): their 2.6 KB come out of the L2 while the 12 KiB of rows per wavefront travel, instead of 2 us before them
@@ -153,15 +156,18 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x / kRow);
     int64_t q_raw = (int64_t)blockIdx.x * (blockDim.x / kRow) + threadIdx.x / kRow;
     int64_t u_next = 0, v_next = 0;
+    int64_t q_cur = 0, q_next = 0;  // pair index of this / the next position (positions themselves without an order)
     if (q_raw < B) {
-        u_next = links[2 * q_raw];
-        v_next = links[2 * q_raw + 1];
+        q_cur = order ? (int64_t)order[q_raw] : q_raw;
+        u_next = links[2 * q_cur];
+        v_next = links[2 * q_cur + 1];
     }
+    if (q_raw + stride < B) q_next = order ? (int64_t)order[q_raw + stride] : q_raw + stride;
     // the trip count is WORKGROUP-UNIFORM (q_raw - group index is the same for every thread): stage_tables(), which contains a
     // __syncthreads(), runs inside the first iteration and relies on exactly that
     for (; q_raw - (threadIdx.x / kRow) < B; q_raw += stride) {
     const bool q_ok = q_raw < B;
-    const int64_t q = q_ok ? q_raw : B - 1;
+    const int64_t q = q_ok ? q_cur : B - 1;
     int64_t u = q_ok ? u_next : 0, v = q_ok ? v_next : 0;
     u = u < 0 ? u + N : u;  // torch-style negative indexing
     v = v < 0 ? v + N : v;
@@ -190,9 +196,11 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
             }
         }
         if (q_raw + stride < B) {  // ids of this group's next pair (returns after the rows above: vmcnt is in order)
-            u_next = links[2 * (q_raw + stride)];
-            v_next = links[2 * (q_raw + stride) + 1];
+            u_next = links[2 * q_next];
+            v_next = links[2 * q_next + 1];
         }
+        q_cur = q_next;
+        if (q_raw + 2 * stride < B) q_next = order ? (int64_t)order[q_raw + 2 * stride] : q_raw + 2 * stride;  // one position further ahead
         if (!staged) {  // workgroup-uniform (the trip count is): the barrier inside is reached by every thread
             est = stage_tables(lds, prm);
             staged = true;
@@ -230,9 +238,11 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
             }
     } else {
         if (q_raw + stride < B) {
-            u_next = links[2 * (q_raw + stride)];
-            v_next = links[2 * (q_raw + stride) + 1];
+            u_next = links[2 * q_next];
+            v_next = links[2 * q_next + 1];
         }
+        q_cur = q_next;
+        if (q_raw + 2 * stride < B) q_next = order ? (int64_t)order[q_raw + 2 * stride] : q_raw + 2 * stride;
         if (!staged) {
             est = stage_tables(lds, prm);
             staged = true;
@@ -312,10 +322,183 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__res
     }  // pairs of this lane group
 }
 
+// ---- run-aware query: consecutive pairs that share their first node reuse its rows ------------------------------------------
+// BUDDY's link sets repeat every source node many times (ogbl-citation2's evaluation set lists 1 000 negatives per source; any
+// coalesced edge list is ordered by source; ss_group_links_by_source puts an arbitrary link set into that form): half of the bytes
+// of a pair are rows of u that the previous pair has just read.  Here a 16-lane group takes a CONTIGUOUS chunk of K <= 16 pairs
+// (positions t of `order` when given, else pairs themselves), lane l fetches the ids of the chunk's l-th pair with one coalesced
+// load, and the group walks the chunk keeping u's MinHash rows, HLL digests and cardinalities in registers while u does not
+// change: such a pair costs H * R + 8 + 4H + 4H(H+2) bytes instead of 2H * R + ... (2 412 instead of 4 708 at H = 3).  A pair's
+// features depend on its own rows only, so rows are bit-identical to pair_features_kernel's whatever the order or the chunking.
+// CAP: ask the register allocator for 4 (H <= 2) / 3 (H = 3) wavefronts per SIMD (some spills) instead of 3 / 2
+template <int H, int TP, int TM, bool CAP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAP ? (H == 3 ? 3 : 4) : 1))) void pair_features_runs_kernel(const int64_t *__restrict__ links, const int32_t *__restrict__ order,
+                                                                 int64_t B, int64_t N, int K, PairTables tabs,
+                                                                 const float *__restrict__ cards, int64_t cards_stride, ss_hll_params prm,
+                                                                 uint32_t flags, float *__restrict__ out, int32_t *__restrict__ err,
+                                                                 const float *__restrict__ degrees)
+{
+    __shared__ EstimatorLds lds;
+    EstimatorTables est = {};
+    bool staged = false;
+    constexpr int NF = H * (H + 2);
+    constexpr int NC = H * H;
+    constexpr int CMPL = TP / 4 / kRow;   // MinHash chunks per lane
+    constexpr int CHPL = TM / 16 / kRow;  // HLL chunks per lane
+    static_assert(CMPL >= 1 && CHPL >= 1 && (TP / 4) % kRow == 0 && (TM / 16) % kRow == 0, "fast path shape");
+    const int l = threadIdx.x & (kRow - 1);
+    const int row_base = (threadIdx.x & (kWave - 1)) & ~(kRow - 1);
+    const int64_t n_groups = (int64_t)gridDim.x * (blockDim.x / kRow);
+    const int64_t n_chunks = (B + K - 1) / K;
+    const float nan = __uint_as_float(0x7FC00000u);
+    // workgroup-uniform trip count (stage_tables() below contains a barrier): every group of the workgroup runs the same number
+    // of outer iterations, groups past the end walk an empty chunk
+    for (int64_t c0 = (int64_t)blockIdx.x * (blockDim.x / kRow); c0 < n_chunks; c0 += n_groups) {
+        const int64_t chunk = c0 + threadIdx.x / kRow;
+        const int64_t base = chunk * K;
+        const int cnt = chunk < n_chunks ? (int)(B - base < K ? B - base : K) : 0;
+        // lane l: position, ids and validity of the chunk's l-th pair
+        int64_t q_l = 0;
+        int u_l = -1, v_l = -1;
+        if (l < cnt) {
+            q_l = order ? (int64_t)order[base + l] : base + l;
+            int64_t u = links[2 * q_l], v = links[2 * q_l + 1];
+            u = u < 0 ? u + N : u;  // torch-style negative indexing
+            v = v < 0 ? v + N : v;
+            if ((uint64_t)u < (uint64_t)N && (uint64_t)v < (uint64_t)N) {
+                u_l = (int)u;
+                v_l = (int)v;
+            } else if (err) {
+                *err = 1;
+            }
+        }
+        int prev_u = -1;
+        // what stays in registers while u does not change: its MinHash rows, its RAW HLL rows (4 registers per chunk; their
+        // digests -- 9 -- are remade for every pair: ~20 instructions per chunk against a third wavefront per SIMD) and its cards
+        u32x4 mu[H][CMPL], xu[H][CHPL];
+        float c1[H];
+        for (int t = 0; t < K; ++t) {  // workgroup-uniform
+            const int u = __shfl(u_l, row_base + t), v = __shfl(v_l, row_base + t);
+            const int q_lo = __shfl((int)q_l, row_base + t), q_hi = __shfl((int)(q_l >> 32), row_base + t);
+            const int64_t q = ((int64_t)q_hi << 32) | (uint32_t)q_lo;
+            const bool live = t < cnt;      // group-uniform
+            const bool bad = u < 0;          // group-uniform
+            const bool fresh = live && !bad && u != prev_u;
+            const int64_t ur = bad ? 0 : u, vr = bad ? 0 : v;  // (a bad pair's rows are requested -- node 0's -- and never used)
+            u32x4 mv[H][CMPL], xv[H][CHPL];
+            if (fresh) {
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+#pragma unroll
+                    for (int c = 0; c < CMPL; ++c) mu[k][c] = *reinterpret_cast<const u32x4 *>(tabs.mh[k] + ur * TP + 4 * (l + kRow * c));
+#pragma unroll
+                    for (int c = 0; c < CHPL; ++c) xu[k][c] = *reinterpret_cast<const u32x4 *>(tabs.hll[k] + ur * TM + 16 * (l + kRow * c));
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+#pragma unroll
+                    for (int c = 0; c < CMPL; ++c) mv[k][c] = *reinterpret_cast<const u32x4 *>(tabs.mh[k] + vr * TP + 4 * (l + kRow * c));
+#pragma unroll
+                    for (int c = 0; c < CHPL; ++c) xv[k][c] = *reinterpret_cast<const u32x4 *>(tabs.hll[k] + vr * TM + 16 * (l + kRow * c));
+                }
+            }
+            if (!staged) {  // first pair of the workgroup: the tables travel under the rows requested above
+                est = stage_tables(lds, prm);
+                staged = true;
+            }
+            if (!live) continue;  // (no barrier below)
+            if (bad) {             // ids out of range: a NaN row, reported through err; u's rows stay valid for the next pair
+                if (degrees) {
+                    if (l < 2 * NF) out[q * (2 * NF) + l] = nan;
+                    if (l + kRow < 2 * NF) out[q * (2 * NF) + l + kRow] = nan;
+                } else if (l < NF) {
+                    out[q * NF + l] = nan;
+                }
+                continue;
+            }
+            float c2[H];
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                if (fresh) c1[k] = cards[ur * cards_stride + k];
+                c2[k] = cards[vr * cards_stride + k];
+            }
+            if (fresh) prev_u = u;
+            int mz[NC];
+            float hs[NC];
+            {
+                int match[NC];
+#pragma unroll
+                for (int k1 = 0; k1 < H; ++k1)
+#pragma unroll
+                    for (int k2 = 0; k2 < H; ++k2) {
+                        int m = 0;
+#pragma unroll
+                        for (int c = 0; c < CMPL; ++c) m += eq4(mu[k1][c], mv[k2][c]);
+                        match[k1 * H + k2] = m;
+                    }
+                HllChunk hv[H][CHPL];
+#pragma unroll
+                for (int k = 0; k < H; ++k)
+#pragma unroll
+                    for (int c = 0; c < CHPL; ++c) hv[k][c] = digest_chunk(xv[k][c]);
+#pragma unroll
+                for (int k1 = 0; k1 < H; ++k1) {
+                    HllChunk hu[CHPL];  // one row of u at a time: its digest lives for H unions only
+#pragma unroll
+                    for (int c = 0; c < CHPL; ++c) hu[c] = digest_chunk(xu[k1][c]);
+#pragma unroll
+                    for (int k2 = 0; k2 < H; ++k2) {
+                        int zeros = 0;
+                        float hsum = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < CHPL; ++c) union_stats_digested(hu[c], hv[k2][c], zeros, hsum);
+                        mz[k1 * H + k2] = row16_sum_i((match[k1 * H + k2] << 20) | zeros);
+                        hs[k1 * H + k2] = row16_sum_f(hsum);
+                    }
+                }
+            }
+            // lane c < H^2 finishes combination c, exactly as pair_features_kernel does
+            int my_mz = mz[0];
+            float my_hs = hs[0];
+#pragma unroll
+            for (int c = 1; c < NC; ++c) {
+                my_mz = (l == c) ? mz[c] : my_mz;
+                my_hs = (l == c) ? hs[c] : my_hs;
+            }
+            float my_I = 0.0f;
+            if (l < NC) {
+                const float jac = (float)(int)((uint32_t)my_mz >> 20) / (float)TP;
+                my_I = jac * hll_estimate(est, my_mz & 0xFFFFF, my_hs);
+            }
+            float I[H][H];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) I[c / H][c % H] = __shfl(my_I, row_base + c);
+            float f[NF];
+            assemble_features<H>(I, c1, c2, flags, f);
+            float my_f = f[0];
+#pragma unroll
+            for (int k = 1; k < NF; ++k) my_f = (l == k) ? f[k] : my_f;
+            if (degrees) {  // fused BUDDY._append_degree_normalised, as in pair_features_kernel
+                const float normaliser = sqrtf(degrees[ur] * degrees[vr]);
+                float normed = my_f / normaliser;
+                if (isnan(normed) || isinf(normed)) normed = 0.0f;
+                if (l < NF) {
+                    out[q * (2 * NF) + l] = my_f;
+                    out[q * (2 * NF) + NF + l] = normed;
+                }
+            } else if (l < NF) {
+                out[q * NF + l] = my_f;
+            }
+        }
+    }
+}
+
 template <int H, int TP, int TM>
 int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &tabs, int P, int M, const float *cards,
                  int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *dbg_match,
-                 int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream)
+                 int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream, const int32_t *order = nullptr)
 {
     const int pairs_per_block = 256 / kRow;
     // pairs per 16-lane group the grid is sized for: ONE while that still fits the chip in a single round of workgroups (ELPH
@@ -335,7 +518,7 @@ int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &t
     {
         ProfileSpan span(stream, SS_PROF_PAIRS);
         hipLaunchKernelGGL((pair_features_kernel<H, TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, links, B, N, tabs, P, M,
-                           cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees);
+                           cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees, order);
     }
     SS_LAUNCH_CHECK();
     return SS_OK;
@@ -344,19 +527,59 @@ int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &t
 template <int H>
 int dispatch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &tabs, int P, int M, const float *cards,
                    int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *dbg_match,
-                   int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream)
+                   int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream, const int32_t *order = nullptr)
 {
 #define SS_PAIRS_FAST(TP)                                                                                                      \
     if (P == TP && M == 256)                                                                                                    \
         return launch_pairs<H, TP, 256>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero,     \
-                                        dbg_inter, err, degrees, stream);
+                                        dbg_inter, err, degrees, stream, order);
     SS_PAIRS_FAST(128)  // the reference's default shape
     SS_PAIRS_FAST(64)   // the other permutation counts the first hop is specialised for (ss_first_hop: P / 64 = 1 .. 4)
     SS_PAIRS_FAST(192)
     SS_PAIRS_FAST(256)
 #undef SS_PAIRS_FAST
     return launch_pairs<H, 0, 0>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter,
-                                 err, degrees, stream);
+                                 err, degrees, stream, order);
+}
+
+template <int H, int TP>
+int launch_pair_runs(const int64_t *links, const int32_t *order, int64_t B, int64_t N, const PairTables &tabs, const float *cards,
+                     int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *err, const float *degrees,
+                     hipStream_t stream)
+{
+    // pairs per chunk: 16 once that still leaves >= 32 768 chunks (eight rounds of 16-group workgroups over 256 CUs); fewer for
+    // smaller batches so that the chip stays full.  SS_PAIR_RUN_CHUNK: tuning hook
+    static const int k_env = getenv("SS_PAIR_RUN_CHUNK") ? atoi(getenv("SS_PAIR_RUN_CHUNK")) : 0;
+    int64_t K = k_env > 0 && k_env <= kRow ? k_env : B / 32768;
+    K = K < 1 ? 1 : (K > kRow ? kRow : K);
+    const int64_t chunks = (B + K - 1) / K;
+    int64_t blocks = (chunks + 256 / kRow - 1) / (256 / kRow);
+    if (blocks > kPairGrid) blocks = kPairGrid;
+    static const bool cap = !(getenv("SS_PAIR_RUN_CAP") && atoi(getenv("SS_PAIR_RUN_CAP")) == 0);
+    {
+        ProfileSpan span(stream, SS_PROF_PAIRS);
+        if (cap)
+            hipLaunchKernelGGL((pair_features_runs_kernel<H, TP, 256, true>), dim3((unsigned)blocks), dim3(256), 0, stream, links, order, B, N, (int)K,
+                               tabs, cards, cards_stride, prm, flags, out, err, degrees);
+        else
+            hipLaunchKernelGGL((pair_features_runs_kernel<H, TP, 256, false>), dim3((unsigned)blocks), dim3(256), 0, stream, links, order, B, N, (int)K,
+                               tabs, cards, cards_stride, prm, flags, out, err, degrees);
+    }
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+template <int H>
+int dispatch_pair_runs(const int64_t *links, const int32_t *order, int64_t B, int64_t N, const PairTables &tabs, int P, const float *cards,
+                       int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *err, const float *degrees,
+                       hipStream_t stream)
+{
+    switch (P) {
+        case 64: return launch_pair_runs<H, 64>(links, order, B, N, tabs, cards, cards_stride, prm, flags, out, err, degrees, stream);
+        case 128: return launch_pair_runs<H, 128>(links, order, B, N, tabs, cards, cards_stride, prm, flags, out, err, degrees, stream);
+        case 192: return launch_pair_runs<H, 192>(links, order, B, N, tabs, cards, cards_stride, prm, flags, out, err, degrees, stream);
+        default: return launch_pair_runs<H, 256>(links, order, B, N, tabs, cards, cards_stride, prm, flags, out, err, degrees, stream);
+    }
 }
 
 }  // namespace ss
@@ -364,7 +587,7 @@ int dispatch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables 
 static int pair_features_impl(const int64_t *links, int64_t B, int64_t N, int32_t h, const uint32_t *const *mh, int32_t P,
                               const uint8_t *const *hll, const float *cards, int64_t cards_stride, const ss_hll_params *prm,
                               uint32_t flags, const float *degrees, float *out, int32_t *dbg_match, int32_t *dbg_zero,
-                              float *dbg_inter, int32_t *err_flag, void *stream)
+                              float *dbg_inter, int32_t *err_flag, void *stream, const int32_t *order = nullptr)
 {
     using namespace ss;
     if (h < 1 || h > SS_MAX_HOPS) return SS_ERR_UNSUPPORTED;  // hashing.py:54, 308-309
@@ -383,9 +606,9 @@ static int pair_features_impl(const int64_t *links, int64_t B, int64_t N, int32_
     const int M = 1 << prm->p;
     hipStream_t s = (hipStream_t)stream;
     switch (h) {
-        case 1: return dispatch_pairs<1>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s);
-        case 2: return dispatch_pairs<2>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s);
-        default: return dispatch_pairs<3>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s);
+        case 1: return dispatch_pairs<1>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s, order);
+        case 2: return dispatch_pairs<2>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s, order);
+        default: return dispatch_pairs<3>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s, order);
     }
 }
 
@@ -407,4 +630,121 @@ extern "C" int ss_pair_features_normalised(const int64_t *links, int64_t B, int6
     if (!degrees) return SS_ERR_INVALID_ARG;
     return pair_features_impl(links, B, N, h, mh, P, hll, cards, cards_stride, prm, flags, degrees, out, nullptr, nullptr, nullptr,
                               err_flag, stream);
+}
+
+// The query over a link list whose pairs are walked in runs of equal first nodes (see pair_features_runs_kernel): `order`
+// (nullable) = a permutation of the pair indices, e.g. from ss_group_links_by_source; without it the pairs are walked as they
+// are listed (a coalesced edge list, or an evaluation set that lists all negatives of a source together, already has the
+// runs).  Row q of `out` is pair q whatever the order; rows are bit-identical to ss_pair_features[_normalised]'s.  degrees
+// nullable (non-null: the degree-normalised copy is appended, as ss_pair_features_normalised does).  Shapes without a
+// specialised kernel (P not in {64, 128, 192, 256} or p != 8) take the ordinary path -- same rows, no reuse.
+// ---- the two permutations around a grouped query over a link set too large for its caches -------------------------------------
+// Walking `order` directly makes every position read links[order[t]] (16 B) and write out[order[t]] (<= 120 B) at random places
+// of arrays of gigabytes (ogbl-citation2: 5.7 GB of links, 21 GB of features): gfx9 counts loads and stores in ONE in-order
+// counter, so the next pair's rows wait behind the previous pair's scattered store and its address translation -- measured 0.69
+// against 1.63 G pairs/s for the same kernel on a link set that fits the Infinity Cache.  These two kernels do the same
+// permutations as dedicated streaming passes (every access independent, thousands in flight per CU) around a query over the
+// gathered -- now contiguous -- chunk.
+namespace ss {
+
+__global__ __launch_bounds__(256) void gather_links_kernel(const int64_t *__restrict__ links, const int32_t *__restrict__ order, int64_t n,
+                                                           int64_t *__restrict__ out)
+{
+    typedef int64_t i64x2 __attribute__((ext_vector_type(2)));
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<i64x2 *>(out)[t] = reinterpret_cast<const i64x2 *>(links)[order[t]];
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float *__restrict__ rows, const int32_t *__restrict__ order, int64_t n, int width,
+                                                           float *__restrict__ out)
+{
+    const int64_t total = n * width;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = e / width;
+        out[(int64_t)order[t] * width + (e - t * width)] = rows[e];
+    }
+}
+
+}  // namespace ss
+
+// out_links[t] := links[order[t]] (int64 [n, 2]);  out[order[t], :] := rows[t, :] (float [n, width]).  See above.
+extern "C" int ss_gather_links(const int64_t *links, const int32_t *order, int64_t n, int64_t *out_links, void *stream)
+{
+    if (n < 0 || (n > 0 && (!links || !order || !out_links))) return SS_ERR_INVALID_ARG;
+    if (n == 0) return SS_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(ss::gather_links_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, links, order, n, out_links);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+extern "C" int ss_scatter_feature_rows(const float *rows, const int32_t *order, int64_t n, int32_t width, float *out, void *stream)
+{
+    if (n < 0 || width <= 0 || (n > 0 && (!rows || !order || !out))) return SS_ERR_INVALID_ARG;
+    if (n == 0) return SS_OK;
+    int64_t blocks = (n * width + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(ss::scatter_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, order, n, (int)width, out);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+static int pair_features_grouped_impl(int which /* -1: chosen per hop count, 0: ordinary kernel, 1: run-aware kernel */, const int64_t *links,
+                                      const int32_t *order, int64_t B, int64_t N, int32_t h, const uint32_t *const *mh, int32_t P,
+                                      const uint8_t *const *hll, const float *cards, int64_t cards_stride, const ss_hll_params *prm,
+                                      uint32_t flags, const float *degrees, float *out, int32_t *err_flag, void *stream)
+{
+    using namespace ss;
+    if (h < 1 || h > SS_MAX_HOPS) return SS_ERR_UNSUPPORTED;
+    if (B < 0 || N < 0) return SS_ERR_INVALID_ARG;
+    const int rc = check_params(prm);
+    if (rc != SS_OK) return rc;
+    if (B == 0) return SS_OK;
+    if (N == 0 || N >= ((int64_t)1 << 31) || !links || !mh || !hll || !cards || !out || cards_stride < h) return SS_ERR_INVALID_ARG;
+    if (P <= 0 || (P & 3) || P > 2048) return SS_ERR_INVALID_ARG;
+    const bool fast = prm->p == 8 && (P == 64 || P == 128 || P == 192 || P == 256);
+    // Which kernel (measured, tools/probe_pair_runs.py -> profiles/round3_pair_runs_*.json, 4 M links): WITH an order the ordinary
+    // kernel -- neighbouring lane groups take neighbouring positions, so the rows of a shared first node meet in the CU's L1 / the
+    // L2 -- is ahead or level at every hop count (ppa-size tables, h = 2, random links grouped: 2.69 against 2.63 G pairs/s;
+    // citation2-size, h = 3: 1.63 against 1.51); WITHOUT one (runs as listed: a coalesced edge list, an evaluation set) the
+    // run-aware kernel wins at h <= 2 (3.49 against 3.24 G pairs/s) and loses at h = 3, where its registers leave two wavefronts
+    // per SIMD (1.73 against 1.93).  SS_PAIR_GROUPED_KERNEL = runs | plain forces one.
+    static const char *forced = getenv("SS_PAIR_GROUPED_KERNEL");
+    const bool runs = fast && (which >= 0 ? which == 1 : (forced ? !strcmp(forced, "runs") : (order == nullptr && h <= 2)));
+    if (!runs) {
+        if (order && B >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
+        return pair_features_impl(links, B, N, h, mh, P, hll, cards, cards_stride, prm, flags, degrees, out, nullptr, nullptr, nullptr,
+                                  err_flag, stream, order);
+    }
+    PairTables tabs = {};
+    for (int k = 0; k < h; ++k) {
+        if (!mh[k] || !hll[k]) return SS_ERR_INVALID_ARG;
+        tabs.mh[k] = mh[k];
+        tabs.hll[k] = hll[k];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (h) {
+        case 1: return dispatch_pair_runs<1>(links, order, B, N, tabs, P, cards, cards_stride, *prm, flags, out, err_flag, degrees, s);
+        case 2: return dispatch_pair_runs<2>(links, order, B, N, tabs, P, cards, cards_stride, *prm, flags, out, err_flag, degrees, s);
+        default: return dispatch_pair_runs<3>(links, order, B, N, tabs, P, cards, cards_stride, *prm, flags, out, err_flag, degrees, s);
+    }
+}
+
+extern "C" int ss_pair_features_grouped(const int64_t *links, const int32_t *order, int64_t B, int64_t N, int32_t h,
+                                        const uint32_t *const *mh, int32_t P, const uint8_t *const *hll, const float *cards,
+                                        int64_t cards_stride, const ss_hll_params *prm, uint32_t flags, const float *degrees, float *out,
+                                        int32_t *err_flag, void *stream)
+{
+    return pair_features_grouped_impl(-1, links, order, B, N, h, mh, P, hll, cards, cards_stride, prm, flags, degrees, out, err_flag, stream);
+}
+
+// measurement / test hook (subgraph_sketch_debug.h): the same call with the kernel forced -- 0 ordinary, 1 run-aware
+extern "C" int ss_pair_features_grouped_kernel(int32_t which, const int64_t *links, const int32_t *order, int64_t B, int64_t N, int32_t h,
+                                               const uint32_t *const *mh, int32_t P, const uint8_t *const *hll, const float *cards,
+                                               int64_t cards_stride, const ss_hll_params *prm, uint32_t flags, const float *degrees,
+                                               float *out, int32_t *err_flag, void *stream)
+{
+    if (which != 0 && which != 1) return SS_ERR_INVALID_ARG;
+    return pair_features_grouped_impl(which, links, order, B, N, h, mh, P, hll, cards, cards_stride, prm, flags, degrees, out, err_flag, stream);
 }

@@ -335,6 +335,39 @@ def unpack_minhash(x_u32):
     return out
 
 
+# Link sets of at least this many pairs are walked GROUPED BY THEIR FIRST NODE (ss_group_links_by_source + ss_pair_features_grouped):
+# BUDDY's precompute hands get_subgraph_features every link of a split (reference datasets/elph.py:207-208) and every source
+# occurs many times -- 120 times on average in ogbl-citation2's 356 M links -- so the rows of u are read once per GROUP instead
+# of once per pair (they meet in the L1 / L2, or stay in registers).  The whole set is grouped at once (not chunk by chunk: a chunk
+# of 11 M links holds a source 3.8 times, the set 120 times); `batch_size` then only bounds the pairs per launch.  Rows are
+# bit-identical and in the caller's order.  The grouping costs ~35 ps per link (0.15 ms for 4 M links); SS_GROUP_LINKS_MIN=0 disables.
+GROUP_LINKS_MIN = int(os.environ.get('SS_GROUP_LINKS_MIN', str(1 << 20)))
+# from this many links on, the grouped query does not walk the order itself: every chunk's links are gathered first and its rows
+# scattered afterwards by two streaming kernels (ss_gather_links / ss_scatter_feature_rows): random 16-byte reads and 60-byte
+# writes over arrays of gigabytes from inside the query's latency chain cost it more than half its rate (csrc/ss_pairs.hip)
+GROUP_GATHER_MIN = int(os.environ.get('SS_GROUP_GATHER_MIN', str(1 << 24)))
+
+
+def group_links_by_source(links, num_nodes, device=None):
+    """int32 [L] permutation of the pair indices of `links` (int64 [L, 2] on the device) in which the pairs of one first node
+    are consecutive (torch-style negative ids wrapped, ids out of range grouped with node 0 -- nothing is dropped)"""
+    device = device or links.device
+    lib = _native.lib()
+    L = links.size(0)
+    if L >= 1 << 31:
+        raise ValueError('link sets of 2^31 pairs and more cannot be grouped in one call')
+    order = torch.empty(max(L, 1), dtype=torch.int32, device=device)
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=device)
+    ws_bytes = lib.ss_csr_workspace_bytes(num_nodes, L)
+    if ws_bytes == 0:
+        raise NotImplementedError(f'link grouping is not supported for {num_nodes} nodes')
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    with _Span('group_links', device):
+        _native.check(lib.ss_group_links_by_source(_ptr(links), L, num_nodes, _ptr(order), _ptr(rowptr), _ptr(ws), ws_bytes, _stream(device)),
+                      'ss_group_links_by_source')
+    return order[:L]
+
+
 LAZY_MINHASH = True  # minhash_prop returns its int64 result as a LazyMinhash (materialised on first outside use)
 # ELPH.forward (reference models/elph.py:209-212) calls hll_prop then minhash_prop per hop.  With this on, the hop-1 minhash_prop
 # (input: an unmodified hop-0 tensor) only RECORDS its work; the hop-2 hll_prop that follows on the same edge_index computes the
@@ -812,6 +845,9 @@ class ElphHashes(object):
         # synchronising 4-byte read per CSR build / query call); False = never reported (edges dropped, NaN feature rows)
         self.strict_bounds = 'deferred'
         self._deferred = _DeferredErrors()
+        # link sets of >= GROUP_LINKS_MIN pairs: 'auto' = grouped by their first node unless the list already has its runs (one
+        # host read per such call), True = always grouped, False = walked as listed (no host read)
+        self.group_links = 'auto'
 
     # no device handles in pickled state (SURVEY.md section 8(b) threading row)
     def __getstate__(self):
@@ -1069,8 +1105,10 @@ class ElphHashes(object):
                 raise ValueError('hash tables of different hops must have the same shape')
         return mh, hll, N, P
 
-    def _pair_kernel(self, links, hash_table, cards, want_debug=False, degrees=None, floor_sf=None):
-        """runs ss_pair_features for links [B,2]; returns (features [B,nf] (or [B,2nf] with degrees) on device, debug dict or None)"""
+    def _pair_kernel(self, links, hash_table, cards, want_debug=False, degrees=None, floor_sf=None, group_batch=None):
+        """runs ss_pair_features for links [B,2]; returns (features [B,nf] (or [B,2nf] with degrees) on device, debug dict or None).
+        group_batch: the links are first grouped by their first node and walked in that order, `group_batch` pairs per launch
+        (GROUP_LINKS_MIN; same rows, in the caller's order)"""
         # where the links live, else where the packed tables already are, else cards, else the current device
         first = hash_table.get(1) if hasattr(hash_table, 'get') else None
         device = _compute_device(links, first.mh_u32 if isinstance(first, HopSketch) else None, cards)
@@ -1108,10 +1146,47 @@ class ElphHashes(object):
         strict, err = self._bounds(device, f'get_subgraph_features({B} links, num_nodes={N})')
         if strict:
             err = _error_flag(device)  # (non-strict launches never touch the shared flag)
+        dg = None
         if degrees is not None:
             dg = degrees.to(device=device, dtype=torch.float32).contiguous()
             if dg.dim() != 1 or dg.numel() != N:
                 raise ValueError(f'degrees must have shape [{N}], got {tuple(dg.shape)}')
+        if group_batch and not want_debug and 1 < B < (1 << 31) and N < (1 << 31):
+            # a list that already has its runs (a coalesced edge list, an evaluation set listing every source's negatives together)
+            # is walked as it is: grouping it again costs ~8 % and scatters the output rows.  One small reduction + ONE host read
+            # per call of >= GROUP_LINKS_MIN links (0.5 ms of query and more); ElphHashes.group_links = True / False skips it.
+            mode = getattr(self, 'group_links', 'auto')  # (instances pickled before the attribute existed)
+            if mode == 'auto':
+                mode = float((lk[1:, 0] == lk[:-1, 0]).sum().item()) < 0.5 * (B - 1)
+            order = group_links_by_source(lk, N, device) if mode else None
+            nf_out = 2 * nf if dg is not None else nf
+            out = torch.empty((B, nf_out), dtype=torch.float32, device=device)
+            for s0 in range(0, B, group_batch):
+                nb = min(group_batch, B - s0)
+                lib = _native.lib()
+                with _Span('pair_features', device):
+                    if order is not None and B >= GROUP_GATHER_MIN:
+                        # a set of gigabytes: gather the chunk's links, query the (now contiguous, grouped) chunk, scatter its rows
+                        o = c_void_p(order.data_ptr() + 4 * s0)
+                        lk_c = torch.empty((nb, 2), dtype=torch.int64, device=device)
+                        rows_c = torch.empty((nb, nf_out), dtype=torch.float32, device=device)
+                        _native.check(lib.ss_gather_links(_ptr(lk), o, nb, _ptr(lk_c), _stream(device)), 'ss_gather_links')
+                        _native.check(lib.ss_pair_features_grouped(_ptr(lk_c), None, nb, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0),
+                                                                   byref(params.struct), flags, _ptr(dg), _ptr(rows_c), _ptr(err),
+                                                                   _stream(device)), 'ss_pair_features_grouped')
+                        _native.check(lib.ss_scatter_feature_rows(_ptr(rows_c), o, nb, nf_out, _ptr(out), _stream(device)), 'ss_scatter_feature_rows')
+                        continue
+                    if order is not None:  # every launch writes rows out[order[s0 + t]] of the ONE output tensor
+                        args = (_ptr(lk), c_void_p(order.data_ptr() + 4 * s0), nb, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0),
+                                byref(params.struct), flags, _ptr(dg), _ptr(out), _ptr(err), _stream(device))
+                    else:                  # as listed: a slice of the links and the matching slice of the output
+                        args = (c_void_p(lk.data_ptr() + 16 * s0), None, nb, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0),
+                                byref(params.struct), flags, _ptr(dg), c_void_p(out.data_ptr() + 4 * nf_out * s0), _ptr(err), _stream(device))
+                    _native.check(lib.ss_pair_features_grouped(*args), 'ss_pair_features_grouped')
+            if strict and _take_error(device):
+                raise IndexError(f'links refer to nodes outside [-{N}, {N})')
+            return out, None
+        if degrees is not None:
             out = torch.empty((B, 2 * nf), dtype=torch.float32, device=device)
             with _Span('pair_features', device):
                 _native.check(_native.lib().ss_pair_features_normalised(
@@ -1228,7 +1303,9 @@ class ElphHashes(object):
             from .feature_store import DeviceFeatureStore
             return DeviceFeatureStore(self, links, hash_table, cards, degrees=degrees, batch_size=batch_size)
         n = links.size(0)
-        if n <= batch_size:
+        if GROUP_LINKS_MIN and n >= GROUP_LINKS_MIN and n < (1 << 31):
+            feats, _ = self._pair_kernel(links, hash_table, cards, degrees=degrees, group_batch=max(int(batch_size), 1))
+        elif n <= batch_size:
             feats, _ = self._pair_kernel(links, hash_table, cards, degrees=degrees)
         else:
             chunks = [self._pair_kernel(links[s:s + batch_size], hash_table, cards, degrees=degrees)[0]
