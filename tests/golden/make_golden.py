@@ -255,6 +255,120 @@ def make_g12():
     print('G12 written')
 
 
+def load_reference_hash_dataset(nan_bias=False):
+    """the reference's own src/datasets/elph.py (HashDataset, BUDDY's feature precompute) on the reference's own src/hashing.py
+    and src/heuristics.py.  Stand-ins for what the image lacks and the precompute does not depend on: torch_geometric.data.Dataset
+    (an empty base class: the reference only uses its constructor and len/get protocol), to_undirected / coalesce (unused: the
+    fixture graphs are undirected and use_coalesce is False), gcn_norm + torch_sparse.spmm (the SIGN node features `x`, NOT part of
+    this fixture -- that row stays pinned by G13's exporter -- are produced by a plain normalised product)."""
+    install_shims(nan_bias)
+    load_reference_buddy()  # stand-ins for the unused PyG imports; puts /root/reference on sys.path
+
+    class Dataset(object):
+        def __init__(self, root=None, *a, **kw):
+            self.root = root
+
+    tgd = types.ModuleType('torch_geometric.data')
+    tgd.Dataset = Dataset
+    sys.modules['torch_geometric.data'] = tgd
+    sys.modules['torch_geometric.utils'].to_undirected = lambda ei, ew=None, *a, **kw: (_ for _ in ()).throw(NotImplementedError())
+    ts = types.ModuleType('torch_sparse')
+    ts.coalesce = lambda *a, **kw: (_ for _ in ()).throw(NotImplementedError())
+
+    def spmm(index, value, m, n, matrix):
+        out = torch.zeros((m, matrix.size(1)), dtype=matrix.dtype)
+        return out.index_add_(0, index[0], value[:, None] * matrix[index[1]])
+    ts.spmm = spmm
+    sys.modules['torch_sparse'] = ts
+    gc = types.ModuleType('torch_geometric.nn.conv.gcn_conv')
+
+    def gcn_norm(edge_index, edge_weight, num_nodes):
+        loops = torch.arange(num_nodes).repeat(2, 1)
+        ei = torch.cat([edge_index, loops], dim=1)
+        ew = torch.cat([edge_weight, torch.ones(num_nodes)])
+        deg = torch.zeros(num_nodes).index_add_(0, ei[1], ew)
+        dis = deg.pow(-0.5)
+        dis[torch.isinf(dis)] = 0
+        return ei, dis[ei[0]] * ew * dis[ei[1]]
+    gc.gcn_norm = gcn_norm
+    sys.modules['torch_geometric.nn.conv.gcn_conv'] = gc
+    for name in ('src.hashing', 'src.datasets.elph', 'src.datasets', 'src.heuristics'):
+        sys.modules.pop(name, None)  # a fresh import against the stand-ins installed above (nan / real bias tables)
+    import src.datasets.elph as ref_ds
+    ref_ds.tqdm = lambda it, **kw: it
+    return ref_ds
+
+
+class _Data(object):
+    """what HashDataset reads of a PyG Data object: attributes + `'edge_weight' in data`"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def __contains__(self, key):
+        return key in self.__dict__
+
+
+def make_g14():
+    """G14: the outputs of the reference's OWN HashDataset (datasets/elph.py:26-85, 175-222: BUDDY's feature precompute, which
+    BASELINE's north_star names) -- subgraph_features after its post-hoc floor / knock-out, degrees, RA, the cache file names --
+    on the BA40 graph (h = 3) and the uniform 3000-node graph (h = 2), for floor_sf x use_zero_one; `*_uses_tables` from the same
+    run with NaN bias tables.  VERDICT r2 missing #3: the reference itself was never run for this call."""
+    import tempfile
+    import warnings
+    import scipy.sparse._index as _spi
+    _orig_validate = _spi.IndexMixin._validate_indices
+
+    def _validate_with_tensors(self, key, *a, **kw):  # (scipy >= 1.13 rejects torch tensors as indices: same values as numpy)
+        conv = (lambda k: k.numpy() if isinstance(k, torch.Tensor) else k)
+        key = tuple(conv(k) for k in key) if isinstance(key, tuple) else conv(key)
+        return _orig_validate(self, key, *a, **kw)
+    _spi.IndexMixin._validate_indices = _validate_with_tensors
+    g = {}
+    graphs = {'ba': (40, ba_graph(40, 5, seed=7), 3, 60), 'uni': (3000, uniform_graph(3000, 12000, seed=1), 2, 700)}
+    for tag, (n, ei, h, n_pos) in graphs.items():
+        rng = np.random.RandomState(14)
+        pos = torch.from_numpy(ei[:, rng.permutation(ei.shape[1])[:n_pos]].T.copy())
+        neg = torch.from_numpy(rng.randint(0, n, size=(n_pos, 2)).astype(np.int64))
+        g[f'{tag}_edge_index'], g[f'{tag}_num_nodes'], g[f'{tag}_hops'] = ei, np.asarray(n), np.asarray(h)
+        g[f'{tag}_pos'], g[f'{tag}_neg'] = pos.numpy(), neg.numpy()
+        for fl in (0, 1):
+            for zo in (0, 1):
+                out = {}
+                for nan_bias in (False, True):
+                    ref_ds = load_reference_hash_dataset(nan_bias)
+                    with tempfile.TemporaryDirectory() as tmp:
+                        root = os.path.join(tmp, 'elph_')
+                        a = Namespace(model='BUDDY', max_hash_hops=h, hll_p=8, minhash_num_perm=128, floor_sf=bool(fl), use_zero_one=bool(zo),
+                                      load_features=False, load_hashes=True, cache_subgraph_features=True, use_feature=True, use_RA=True,
+                                      sign_k=0, num_negs=1, subgraph_feature_batch_size=11000000, dataset_name='synthetic', year=0,
+                                      use_struct_feature=True)
+                        data = _Data(edge_index=torch.from_numpy(ei), num_nodes=n, x=torch.ones((n, 4)))
+                        with warnings.catch_warnings():
+                            warnings.simplefilter('ignore')
+                            ds = ref_ds.HashDataset(root, 'train', data, pos, neg, a)
+                        files = sorted(os.listdir(tmp))
+                        cached = torch.load(os.path.join(tmp, [f for f in files if f.endswith('subgraph_featurecache.pt')][0]))
+                    out[nan_bias] = (ds, files, cached)
+                ds, files, cached = out[False]
+                key = f'{tag}_fl{fl}_zo{zo}'
+                assert ds.subgraph_features.dtype == torch.float32 and ds.subgraph_features.shape == (2 * n_pos, h * (h + 2))
+                g[f'{key}_subgraph_features'] = ds.subgraph_features.numpy()
+                g[f'{key}_uses_tables'] = torch.isnan(out[True][0].subgraph_features).numpy()
+                # what the reference wrote to its feature cache: the tensor BEFORE the post-hoc floor / knock-out? No: torch.save
+                # stores the same tensor object HashDataset then edits in place only AFTER saving (datasets/elph.py:211-222)
+                g[f'{key}_cached_features'] = cached.numpy()
+                g[f'{key}_files'] = np.asarray(files)
+                if fl == 0 and zo == 1:
+                    g[f'{tag}_links'] = ds.links.numpy()
+                    g[f'{tag}_degrees'] = ds.degrees.numpy()
+                    g[f'{tag}_RA'] = ds.RA.numpy()
+                    g[f'{tag}_labels'] = np.asarray(ds.labels)
+    _spi.IndexMixin._validate_indices = _orig_validate
+    np.savez_compressed(os.path.join(HERE, 'g14_hash_dataset.npz'), **g)
+    print('G14 written:', {k: v.shape for k, v in g.items() if k.endswith('subgraph_features')}, g['ba_fl0_zo1_files'])
+
+
 def args(h=2, p=8, P=128, floor_sf=False, use_zero_one=True):
     return Namespace(max_hash_hops=h, hll_p=p, minhash_num_perm=P, floor_sf=floor_sf, use_zero_one=use_zero_one)
 
@@ -479,7 +593,10 @@ if __name__ == '__main__':
         make_g10()
     elif '--only-g12' in sys.argv:
         make_g12()
+    elif '--only-g14' in sys.argv:
+        make_g14()
     else:
         main()
         make_g10()
         make_g12()
+        make_g14()

@@ -333,3 +333,60 @@ def test_pyg_sign_fixture():
         assert np.array_equal(ei, g[f'norm_edge_index_{tag}']), 'gcn_norm: edge order / self-loop placement differs from PyG'
         np.testing.assert_allclose(w, g[f'norm_weight_{tag}'], rtol=2e-6, atol=0)
         np.testing.assert_allclose(oracle.spmm(ei, w, n, g['x']), g[f'spmm_{tag}'], rtol=1e-5, atol=1e-6)
+
+
+def _buddy_precompute_with(compute, g, tag, fl, zo):
+    """HashDataset.__init__'s sketch side re-enacted (reference datasets/elph.py:175-222): build, query every link, then the
+    POST-HOC floor and knock-out on the returned tensor -- the ElphHashes the dataset owns is constructed from the SAME args, so
+    the query has already applied both; the second application must be idempotent"""
+    h = int(g[f'{tag}_hops'])
+    sf = compute(int(g[f'{tag}_num_nodes']), g[f'{tag}_edge_index'], g[f'{tag}_links'], h, bool(fl), bool(zo))
+    sf = np.array(sf, copy=True)
+    if fl:
+        sf[sf < 0] = 0
+    if not zo:
+        if h > 1:
+            sf[:, [4, 5]] = 0
+        if h == 3:
+            sf[:, [11, 12]] = 0
+    return sf
+
+
+def test_buddy_precompute_vs_the_references_hash_dataset(regenerated_tables):
+    """G14 = outputs of the reference's OWN HashDataset (BUDDY's feature precompute, the call BASELINE's north_star names; made
+    by tests/golden/make_golden.py --only-g14 importing src/datasets/elph.py): subgraph_features for floor_sf x use_zero_one,
+    degrees, RA, cache file names.  The oracle through the same sequence of calls."""
+    import scipy.sparse as ssp
+    g = load_golden('g14_hash_dataset.npz')
+    prm = oracle_params(regenerated_tables[8])
+
+    def compute(n, ei, links, h, fl, zo):
+        tables, cards = oracle.build_hash_tables(n, ei, h, 128, prm)
+        return oracle.pair_features(links, tables, cards, h, prm, use_zero_one=zo, floor_sf=fl)
+    for tag in ('ba', 'uni'):
+        n, ei, h = int(g[f'{tag}_num_nodes']), g[f'{tag}_edge_index'], int(g[f'{tag}_hops'])
+        links = g[f'{tag}_links']
+        assert np.array_equal(links, np.concatenate([g[f'{tag}_pos'], g[f'{tag}_neg']]))      # datasets/elph.py:51
+        assert list(g[f'{tag}_labels']) == [1] * len(g[f'{tag}_pos']) + [0] * len(g[f'{tag}_neg'])
+        A = ssp.csr_matrix((np.ones(ei.shape[1], dtype=int), (ei[0], ei[1])), shape=(n, n))    # :62,68-71
+        assert np.array_equal(np.asarray(A.sum(axis=0, dtype=float), dtype=np.float32).ravel(), g[f'{tag}_degrees'])   # :74
+        assert np.array_equal(oracle.common_neighbour_scores(A, links, 'RA'), g[f'{tag}_RA'])  # :76-77
+        hop = '' if h == 2 else f'{h}hop_'
+        for fl in (0, 1):
+            for zo in (0, 1):
+                key = f'{tag}_fl{fl}_zo{zo}'
+                assert list(g[f'{key}_files']) == [f'elph_train_{hop}cardcache.pt', f'elph_train_{hop}hashcache.pt',
+                                                   f'elph_train_{hop}subgraph_featurecache.pt']               # :154-173,187-188
+                want, uses = g[f'{key}_subgraph_features'], g[f'{key}_uses_tables']
+                got = _buddy_precompute_with(compute, g, tag, fl, zo)
+                assert got.shape == want.shape == (len(links), h * (h + 2)) and got.dtype == np.float32
+                assert np.array_equal(got[~uses], want[~uses]), f'{key}: entries independent of the bias tables must be bit-exact'
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-4, err_msg=key)
+                # the reference saves its cache BEFORE the post-hoc edits (:211-213 then :214-222): identical here because the
+                # query already floored / knocked out (the dataset's ElphHashes is built from the same args)
+                assert np.array_equal(g[f'{key}_cached_features'], want)
+                if fl:
+                    assert (want >= 0).all()
+                if not zo:
+                    assert not want[:, [4, 5]].any()
+        assert g[f'{tag}_fl0_zo1_uses_tables'].mean() < 0.9   # a good part of the fixture pins values whatever the tables
