@@ -115,6 +115,16 @@ int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, i
                  int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
                  int32_t *mega_rows, int32_t *mega_count,
                  int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream);
+/* ss_csr_build preceded by a device-side content check: `fingerprint` (device buffer of SS_CSR_FINGERPRINT_BYTES, zeroed by the
+ * caller before its first use and tied to THESE output buffers) holds two 64-bit sums over the edge list the outputs were last
+ * built from; when the sums of (src, dst) agree every kernel of the build exits at once, otherwise the build runs and the sums are
+ * replaced.  ELPH.forward (models/elph.py:186) concatenates the same self-looped edge_index into a fresh tensor every training
+ * step: its CSR costs one 41 MB streaming pass instead of a rebuild.  No host synchronisation. */
+#define SS_CSR_FINGERPRINT_BYTES 8448
+int ss_csr_build_cached(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
+                        int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
+                        int32_t *mega_rows, int32_t *mega_count, int32_t *err_flag, void *workspace, size_t workspace_bytes,
+                        void *fingerprint, void *stream);
 
 /* One hop of sketch propagation over a CSR: out[i] = min (MinHash) / max (HLL) over the in-neighbours
  * of i, plus row i itself when i < n_self_loops (the implicit self loops of add_self_loops,

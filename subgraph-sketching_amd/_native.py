@@ -33,7 +33,7 @@ class CsrGraphStruct(ctypes.Structure):
 
 ABI_VERSION = 124  # ss_version() of the library this module's struct mirrors and signatures describe
 PROF_MINHASH_HOP, PROF_HLL_HOP, PROF_FIRST_HOP_MH, PROF_FIRST_HOP_HLL, PROF_PAIRS, PROF_CSR, PROF_HUB, PROF_FUSED, PROF_MINHASH_ROWS = range(9)  # SS_PROF_* tags
-MEGA_SLICE, MEGA_SLOT_BYTES = 1024, 1280  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
+MEGA_SLICE, MEGA_SLOT_BYTES, CSR_FINGERPRINT_BYTES = 1024, 1280, 8448  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/subgraph_sketch.h and include/subgraph_sketch_debug.h
@@ -45,6 +45,8 @@ SIGNATURES = {
     'ss_csr_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'ss_csr_build': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ss_csr_build_cached': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     'ss_propagate': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p]),
     'ss_minhash_hop_rows': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),

@@ -249,7 +249,14 @@ struct PassArgs {
     const unsigned long long *seg_base;  // pass 2: base1[keys1 + 1]
     int64_t E, N, slice;                 // pass 1
     int shift, sub_shift, keys, parts;   // key = dst >> shift (pass 1) | (dst >> sub_shift) - (bucket << (shift - sub_shift)) (pass 2)
+    const int32_t *skip;                 // nullable: *skip != 0 -> the outputs already hold this CSR (ss_csr_build_cached), every kernel exits
 };
+
+// first statement of every kernel of a build (workgroup-uniform: one word)
+#define SS_CSR_SKIP(word)            \
+    do {                             \
+        if ((word) && *(word)) return; \
+    } while (0)
 
 template <bool PASS2>
 __device__ __forceinline__ void block_range(const PassArgs &a, int64_t &lo, int64_t &hi, int &group, int &part, int &parts)
@@ -286,6 +293,7 @@ __global__ __launch_bounds__(kThreads) void count_keys_kernel(PassArgs a, uint32
                                                               int32_t *__restrict__ mega_count, int32_t *__restrict__ dense_count)
 {
     __shared__ uint32_t hist[kMaxKeys];
+    SS_CSR_SKIP(a.skip);
     if (!PASS2 && blockIdx.x == 0 && threadIdx.x == 0) {  // outputs of later kernels of this build are cleared here
         *n_self = 0ULL;
         if (hub_count) *hub_count = 0;
@@ -329,8 +337,9 @@ __global__ __launch_bounds__(kThreads) void count_keys_kernel(PassArgs a, uint32
 
 // pass 1: one wave per key: exclusive scan of that key's counts over the slices (in place) + key total
 __global__ __launch_bounds__(kThreads) void scan_block_counts_kernel(uint32_t *__restrict__ counts, int blocks, int keys,
-                                                                     unsigned long long *__restrict__ key_total)
+                                                                     unsigned long long *__restrict__ key_total, const int32_t *__restrict__ skip)
 {
+    SS_CSR_SKIP(skip);
     const int lane = threadIdx.x & (kWave - 1);
     const int k = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
     if (k >= keys) return;
@@ -353,9 +362,10 @@ __global__ __launch_bounds__(kThreads) void scan_block_counts_kernel(uint32_t *_
 
 // pass 1: single workgroup: key totals -> exclusive bases (in place), grand total appended and written to rowptr[N]
 __global__ __launch_bounds__(kThreads) void scan_bases_kernel(unsigned long long *__restrict__ key_total, int keys,
-                                                              int64_t *__restrict__ rowptr, int64_t N)
+                                                              int64_t *__restrict__ rowptr, int64_t N, const int32_t *__restrict__ skip)
 {
     __shared__ unsigned long long vals[kMaxKeys];
+    SS_CSR_SKIP(skip);
     vals[threadIdx.x] = (int)threadIdx.x < keys ? key_total[threadIdx.x] : 0ULL;
     __syncthreads();
     if (threadIdx.x == 0) {  // <= 256 values: a serial scan is a few hundred cycles
@@ -377,9 +387,10 @@ __global__ __launch_bounds__(kThreads) void scan_bases_kernel(unsigned long long
 __global__ __launch_bounds__(kThreads) void scan_sub_counts_kernel(uint32_t *__restrict__ counts2, int keys2, int parts2,
                                                                    const unsigned long long *__restrict__ base1,
                                                                    unsigned long long *__restrict__ fine_base, int64_t fine_buckets,
-                                                                   int keys1)
+                                                                   int keys1, const int32_t *__restrict__ skip)
 {
     __shared__ uint32_t wave_tot[kThreads / kWave];
+    SS_CSR_SKIP(skip);
     const int c = blockIdx.x;
     uint32_t *m = counts2 + (int64_t)c * keys2 * parts2;
     uint32_t sum = 0;  // thread k owns key k: its parts2 counters are consecutive
@@ -411,6 +422,7 @@ __global__ __launch_bounds__(kScatterThreads) void scatter_tiles_kernel(PassArgs
     __shared__ uint32_t tile_hist[kMaxKeys], tile_off[kMaxKeys], wave_tot[kScatterThreads / kWave];
     __shared__ unsigned long long cursor[kMaxKeys];
     __shared__ unsigned long long block_max;
+    SS_CSR_SKIP(a.skip);
     int64_t lo, hi;
     int group, part, parts;
     block_range<PASS2>(a, lo, hi, group, part, parts);
@@ -575,6 +587,7 @@ struct RowOutputs {
     int64_t *rowptr;
     int hub_threshold;
     int32_t *hub_rows, *hub_count, *mega_rows, *mega_count;
+    const int32_t *skip;  // see PassArgs
 };
 
 // exclusive scan of the per-node edge counts cnt[0..nb) of the bucket that starts at node0 -> excl[0..nb]; with `publish` the
@@ -719,11 +732,13 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
                                                                  int64_t N, int shift, int keys, int tiles, int2 *__restrict__ staged,
                                                                  uint32_t *__restrict__ tile_off, unsigned long long *__restrict__ tile_max,
                                                                  int32_t *__restrict__ err, int32_t *__restrict__ hub_count,
-                                                                 int32_t *__restrict__ mega_count, int32_t *__restrict__ dense_count)
+                                                                 int32_t *__restrict__ mega_count, int32_t *__restrict__ dense_count,
+                                                                 const int32_t *__restrict__ skip)
 {
     __shared__ int2 sorted[kTile];
     __shared__ uint32_t tile_hist[kMaxKeys], tile_offs[kMaxKeys], wave_tot[kSortThreads / kWave];
     __shared__ unsigned long long block_max;
+    SS_CSR_SKIP(skip);
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // outputs of the finish launch of this build are cleared here
         if (hub_count) *hub_count = 0;
         if (mega_count) mega_count[0] = mega_count[1] = 0;
@@ -947,9 +962,10 @@ template <bool GATHER>
 __global__ __launch_bounds__(kFinishThreads) void dense_count_kernel(const int2 *__restrict__ staged, const uint32_t *__restrict__ tile_off,
                                                                      int tiles, int node_shift, const int32_t *__restrict__ dense_count,
                                                                      const DenseBucket *__restrict__ list, uint32_t *__restrict__ node_cnt,
-                                                                     uint32_t *__restrict__ share_off)
+                                                                     uint32_t *__restrict__ share_off, const int32_t *__restrict__ skip)
 {
     __shared__ DenseLds lds;
+    SS_CSR_SKIP(skip);
     dense_count_shares<GATHER>(lds, blockIdx.x, gridDim.x, staged, tile_off, tiles, node_shift, dense_count[0], dense_count[1], list, node_cnt,
                                share_off);
 }
@@ -961,6 +977,7 @@ __global__ __launch_bounds__(kFinishThreads) void dense_place_kernel(const int2 
                                                                      const uint32_t *__restrict__ share_off, int32_t *__restrict__ col, RowOutputs o)
 {
     __shared__ DenseLds lds;
+    SS_CSR_SKIP(o.skip);
     dense_place_shares<GATHER>(lds, blockIdx.x, gridDim.x, staged, tile_off, tiles, node_shift, N, dense_count[0], dense_count[1], list,
                                node_cnt, share_off, col, o);
 }
@@ -1020,6 +1037,7 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__re
                                                                 int64_t n_buckets)
 {
     __shared__ FinishLds lds;
+    SS_CSR_SKIP(o.skip);
     if ((int64_t)blockIdx.x >= n_buckets) {  // helper workgroup (see dense_helper)
         dense_helper<false>(*reinterpret_cast<DenseLds *>(lds.image), (int)(blockIdx.x - n_buckets), (int)n_buckets, staged, nullptr, 0, node_shift,
                             N, col, o, dense);
@@ -1042,6 +1060,7 @@ __global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int
     __shared__ int n_long_s;
     __shared__ unsigned long long red_base[kFinishThreads / kWave], red_max[kFinishThreads / kWave];
     __shared__ uint32_t red_n[kFinishThreads / kWave];
+    SS_CSR_SKIP(o.skip);
     if ((int)blockIdx.x >= keys) {  // helper workgroup (see dense_helper)
         dense_helper<true>(*reinterpret_cast<DenseLds *>(lds.image), (int)blockIdx.x - keys, keys, staged, tile_off, tiles, node_shift, N, col, o,
                            dense);
@@ -1103,6 +1122,78 @@ __global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int
 
 namespace ss {
 
+// ---- content fingerprint of an edge list (ss_csr_build_cached) ---------------------------------------------------------------
+// ELPH.forward concatenates a fresh self-looped edge_index every training step (reference models/elph.py:186) -- the same
+// edges in a new tensor -- and the CSR of it was rebuilt every step (43 us of a 0.30 ms step).  The cached form streams the
+// edge list once (two independent 64-bit sums of a 64-bit mix of every (src, dst): order-independent, like the CSR's meaning),
+// compares them ON THE DEVICE with the sums stored beside the CSR by the build that made it, and lets every kernel of the build
+// exit when they agree.  No host read; an edited or recycled edge_index has other sums and is rebuilt.
+constexpr int kFpBlocks = 512;
+struct FingerprintWords {  // layout of the caller's device buffer (SS_CSR_FINGERPRINT_BYTES)
+    unsigned long long stored[2];
+    int32_t valid, skip;
+    unsigned long long partial[kFpBlocks][2];
+};
+static_assert(sizeof(FingerprintWords) <= SS_CSR_FINGERPRINT_BYTES, "SS_CSR_FINGERPRINT_BYTES");
+
+__global__ __launch_bounds__(256) void fingerprint_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t E,
+                                                          FingerprintWords *__restrict__ fp)
+{
+    __shared__ unsigned long long red[2][256 / kWave];
+    unsigned long long a = 0, b = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t s = (uint64_t)src[e], d = (uint64_t)dst[e];
+        a += hash_u64(s * 0x9E3779B97F4A7C15ULL + d + 0x632BE59BD9B4E019ULL);
+        b += hash_u64((d ^ 0xD6E8FEB86659FD93ULL) * 0xC2B2AE3D27D4EB4FULL + s);
+    }
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        red[0][threadIdx.x / kWave] = a;
+        red[1][threadIdx.x / kWave] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / kWave; ++w) {
+            a += red[0][w];
+            b += red[1][w];
+        }
+        fp->partial[blockIdx.x][0] = a;
+        fp->partial[blockIdx.x][1] = b;
+    }
+}
+
+// one workgroup: sums of the partials (+ the shape, so that another N / E / hub threshold never matches) against the stored
+// ones -> skip word; the new sums are stored: after this build the outputs hold the CSR of THIS edge list either way
+__global__ __launch_bounds__(kFpBlocks) void fingerprint_decide_kernel(FingerprintWords *__restrict__ fp, int64_t E, int64_t N, int hub_threshold)
+{
+    __shared__ unsigned long long red[2][kFpBlocks / kWave];
+    unsigned long long a = fp->partial[threadIdx.x][0], b = fp->partial[threadIdx.x][1];
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        red[0][threadIdx.x / kWave] = a;
+        red[1][threadIdx.x / kWave] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kFpBlocks / kWave; ++w) {
+            a += red[0][w];
+            b += red[1][w];
+        }
+        a ^= hash_u64((uint64_t)E * 0x9E3779B97F4A7C15ULL + (uint64_t)N);
+        b ^= hash_u64((uint64_t)N * 0xC2B2AE3D27D4EB4FULL + (uint64_t)(uint32_t)hub_threshold + ((uint64_t)E << 20));
+        fp->skip = (fp->valid == 1 && fp->stored[0] == a && fp->stored[1] == b) ? 1 : 0;
+        fp->stored[0] = a;
+        fp->stored[1] = b;
+        fp->valid = 1;
+    }
+}
+
 // helper workgroups a finish launch may carry: at most HALF the workgroups of that kernel the device can hold at once (see
 // dense_helper for why that bound excludes a deadlock), at most kDenseHelpers; 0 = use the stand-alone dense launches
 constexpr int kDenseHelpers = 256;
@@ -1145,7 +1236,7 @@ extern "C" size_t ss_csr_workspace_bytes(int64_t N, int64_t E)
 static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                           int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
                           int32_t *mega_rows, int32_t *mega_count,
-                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_);
+                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *skip = nullptr);
 
 extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                             int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
@@ -1155,6 +1246,28 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
     if (E > 0 && !src) return SS_ERR_INVALID_ARG;
     return csr_build_impl(src, dst, E, N, rowptr, col, n_self_loops_out, hub_threshold, hub_rows, hub_count, mega_rows, mega_count, err_flag,
                           workspace, workspace_bytes, stream_);
+}
+
+// ss_csr_build that first compares a content fingerprint of (src, dst) with the one the previous call left in `fingerprint`
+// (device buffer of SS_CSR_FINGERPRINT_BYTES, zeroed by the caller before its first use, tied to THESE output buffers): equal ->
+// the outputs already hold this CSR and every kernel of the build exits at once; different (or first use) -> an ordinary build,
+// after which `fingerprint` describes the new contents.  No host synchronisation either way.  err_flag is only written by a
+// build that runs.  (reference models/elph.py:186 + runners/train.py:188-198: the same edges in a fresh tensor every step)
+extern "C" int ss_csr_build_cached(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
+                                   int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
+                                   int32_t *mega_rows, int32_t *mega_count, int32_t *err_flag, void *workspace, size_t workspace_bytes,
+                                   void *fingerprint, void *stream_)
+{
+    using namespace ss;
+    if (!fingerprint || E <= 0 || N <= 0 || !src || !dst) return SS_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    FingerprintWords *fp = reinterpret_cast<FingerprintWords *>(fingerprint);
+    hipLaunchKernelGGL(fingerprint_kernel, dim3(kFpBlocks), dim3(256), 0, stream, src, dst, E, fp);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fingerprint_decide_kernel, dim3(1), dim3(kFpBlocks), 0, stream, fp, E, N, (int)hub_threshold);
+    SS_LAUNCH_CHECK();
+    return csr_build_impl(src, dst, E, N, rowptr, col, n_self_loops_out, hub_threshold, hub_rows, hub_count, mega_rows, mega_count, err_flag,
+                          workspace, workspace_bytes, stream_, &fp->skip);
 }
 
 // The pairs of a query grouped by their first node (reference hashing.py:270-274 reads cards[u] / the rows of u once per PAIR;
@@ -1174,7 +1287,7 @@ extern "C" int ss_group_links_by_source(const int64_t *links, int64_t B, int64_t
 static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                           int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
                           int32_t *mega_rows, int32_t *mega_count,
-                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_)
+                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *skip)
 {
     using namespace ss;
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || !rowptr) return SS_ERR_INVALID_ARG;
@@ -1195,7 +1308,7 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
     const Workspace w = carve(p, E, workspace);
     ProfileSpan span(stream, SS_PROF_CSR);  // all launches of this build
     unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
-    const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count};
+    const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count, skip};
     // the dense steps loop over the registered shares: no more workgroups than shares can exist
     const int64_t share_cap = max_dense_shares(E);
     const unsigned dense_grid = (unsigned)(share_cap < kDenseGrid ? share_cap : kDenseGrid);
@@ -1205,14 +1318,14 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
 
     if (p.gather) {  // <= 256 fine buckets and <= kMaxTiles tiles: two launches, no counting pass, no scan kernels
         hipLaunchKernelGGL(tile_sort_kernel, dim3(p.tiles), dim3(kSortThreads), 0, stream, src, dst, E, N, p.shift1, p.keys1, p.tiles, w.staged_a,
-                           w.tile_off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count);
+                           w.tile_off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(finish_gather_kernel, dim3((unsigned)(p.fine_buckets + helpers)), dim3(kFinishThreads), 0, stream, w.staged_a,
                            w.tile_off, w.tile_max, p.tiles, p.keys1, p.node_shift, N, col, n_self, rows_out, dense);
         SS_LAUNCH_CHECK();
         if (helpers) return SS_OK;
         hipLaunchKernelGGL(dense_count_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, w.staged_a, w.tile_off, p.tiles,
-                           p.node_shift, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off);
+                           p.node_shift, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, skip);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(dense_place_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, w.staged_a, w.tile_off, p.tiles,
                            p.node_shift, N, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, col, rows_out);
@@ -1221,13 +1334,13 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
     }
     // ---- pass 1 ----
     PassArgs a1 = {};
-    a1.src = src; a1.dst = dst; a1.E = E; a1.N = N; a1.slice = p.slice1; a1.shift = p.shift1; a1.keys = p.keys1;
+    a1.src = src; a1.dst = dst; a1.E = E; a1.N = N; a1.slice = p.slice1; a1.shift = p.shift1; a1.keys = p.keys1; a1.skip = skip;
     hipLaunchKernelGGL(count_keys_kernel<false>, dim3(p.blocks1), dim3(kThreads), 0, stream, a1, w.counts1, err_flag, n_self, hub_count,
                        mega_count, w.dense_count);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_block_counts_kernel, dim3((p.keys1 + 3) / 4), dim3(kThreads), 0, stream, w.counts1, p.blocks1, p.keys1, w.base1);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3((p.keys1 + 3) / 4), dim3(kThreads), 0, stream, w.counts1, p.blocks1, p.keys1, w.base1, skip);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_bases_kernel, dim3(1), dim3(kThreads), 0, stream, w.base1, p.keys1, rowptr, N);
+    hipLaunchKernelGGL(scan_bases_kernel, dim3(1), dim3(kThreads), 0, stream, w.base1, p.keys1, rowptr, N, skip);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(scatter_tiles_kernel<false>, dim3(p.blocks1), dim3(kScatterThreads), 0, stream, a1, w.counts1, w.base1, w.staged_a, n_self,
                        err_flag);
@@ -1238,14 +1351,14 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
     if (p.two_pass) {
         PassArgs a2 = {};
         a2.staged = w.staged_a; a2.seg_base = w.base1; a2.N = N; a2.shift = p.shift1; a2.sub_shift = p.shift2; a2.keys = p.keys2;
-        a2.parts = p.parts2;
+        a2.parts = p.parts2; a2.skip = skip;
         const int64_t buckets2 = p.three_pass ? p.groups3 : p.fine_buckets;  // buckets that exist after pass 2
         const unsigned blocks2 = (unsigned)(p.keys1 * p.parts2);
         hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks2), dim3(kThreads), 0, stream, a2, w.counts2, (int32_t *)nullptr,
                            (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(scan_sub_counts_kernel, dim3(p.keys1), dim3(kThreads), 0, stream, w.counts2, p.keys2, p.parts2, w.base1,
-                           w.fine_base, buckets2, p.keys1);
+                           w.fine_base, buckets2, p.keys1, skip);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks2), dim3(kScatterThreads), 0, stream, a2, w.counts2, w.base1, w.staged_b,
                            (unsigned long long *)nullptr, (int32_t *)nullptr);
@@ -1257,13 +1370,13 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
             if (p.groups3 * p.parts3 >= ((int64_t)1 << 31)) return SS_ERR_UNSUPPORTED;
             PassArgs a3 = {};
             a3.staged = w.staged_b; a3.seg_base = w.fine_base; a3.N = N; a3.shift = p.shift2; a3.sub_shift = p.node_shift; a3.keys = p.keys3;
-            a3.parts = p.parts3;
+            a3.parts = p.parts3; a3.skip = skip;
             const unsigned blocks3 = (unsigned)(p.groups3 * p.parts3);
             hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks3), dim3(kThreads), 0, stream, a3, w.counts3, (int32_t *)nullptr,
                                (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
             SS_LAUNCH_CHECK();
             hipLaunchKernelGGL(scan_sub_counts_kernel, dim3((unsigned)p.groups3), dim3(kThreads), 0, stream, w.counts3, p.keys3, p.parts3,
-                               w.fine_base, w.fine_base3, p.fine_buckets, (int)p.groups3);
+                               w.fine_base, w.fine_base3, p.fine_buckets, (int)p.groups3, skip);
             SS_LAUNCH_CHECK();
             hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks3), dim3(kScatterThreads), 0, stream, a3, w.counts3, w.fine_base, w.staged_a,
                                (unsigned long long *)nullptr, (int32_t *)nullptr);
@@ -1278,7 +1391,7 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
     SS_LAUNCH_CHECK();
     if (helpers) return SS_OK;
     hipLaunchKernelGGL(dense_count_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, final_staged, (const uint32_t *)nullptr, 0,
-                       p.node_shift, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off);
+                       p.node_shift, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, skip);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(dense_place_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, final_staged, (const uint32_t *)nullptr, 0,
                        p.node_shift, N, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, col, rows_out);

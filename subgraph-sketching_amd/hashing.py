@@ -534,6 +534,9 @@ class CsrGraph(object):
         self.mega_rows, self.mega_count, self.mega_scratch = mega if mega is not None else (None, None, None)
         self.has_hub_rows = True  # unknown (no host read of the device counters): keep the hub passes
         self.pending_minhash = None  # (weakref to a LazyMinhash, perms, P, p): a deferred hop-1 MinHash table on this graph
+        self.pending_lazies = []     # weakrefs to every LazyMinhash whose deferred launch refers to this graph
+        self.num_edges = None
+        self.fingerprint = None      # device buffer of ss_csr_build_cached (None: never reused)
         self.use_inferred_self_loops = False
 
     def struct(self, rows=None):
@@ -555,10 +558,35 @@ class CsrGraph(object):
                                       row_begin=begin, row_end=end)
 
 
-def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None, err_flag=None):
+def _rebuild_csr_if_changed(csr, src, dst, err_flag):
+    """ss_csr_build_cached into the buffers of `csr`: a device-side content check, then either nothing or an ordinary build"""
+    lib = _native.lib()
+    device, E, N = csr.rowptr.device, src.numel(), csr.num_nodes
+    # deferred launches that still refer to this CSR run now, while it describes the graph they were recorded on
+    for ref in csr.pending_lazies:
+        lazy = ref()
+        if lazy is not None:
+            lazy.resolve()
+    csr.pending_lazies = []
+    csr.pending_minhash = None
+    ws_bytes = lib.ss_csr_workspace_bytes(N, E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    with _Span('csr_build', device):
+        _native.check(lib.ss_csr_build_cached(_ptr(src), _ptr(dst), E, N, _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.n_self_dev),
+                                              csr.hub_threshold, _ptr(csr.hub_rows), _ptr(csr.hub_count), _ptr(csr.mega_rows),
+                                              _ptr(csr.mega_count), _ptr(err_flag), _ptr(ws), ws_bytes, _ptr(csr.fingerprint),
+                                              _stream(device)), 'ss_csr_build_cached')
+    return csr
+
+
+def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None, err_flag=None, reuse=None, fingerprint=False):
     """CSR-by-destination of edge_index [2, E] (flow source -> target, reference hashing.py:34,44).
     check=True synchronises once to raise IndexError for endpoints outside [0, num_nodes); err_flag (a device-visible
-    int32 tensor, see _DeferredErrors) takes the report instead and nothing synchronises."""
+    int32 tensor, see _DeferredErrors) takes the report instead and nothing synchronises.
+    reuse: a CsrGraph built earlier for the same shape (num_nodes, number of edges, device, hub threshold) by a non-strict build:
+    its buffers are rebuilt only if the CONTENT of edge_index differs (device-side fingerprint, no host read) -- ELPH.forward hands
+    over the same self-looped edges in a fresh tensor every training step (reference models/elph.py:186).
+    fingerprint=True: this build leaves the sums behind that a later `reuse` compares with (one extra streaming pass over the edges)"""
     lib = _native.lib()
     ei = edge_index.to(device=device, dtype=torch.int64)
     if ei.dim() != 2 or ei.size(0) != 2:
@@ -567,6 +595,9 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None, err
     E = src.numel()
     if hub_threshold is None:
         hub_threshold = HUB_THRESHOLD if HUB_THRESHOLD is not None else default_hub_threshold(E)
+    if (reuse is not None and not check and E > 0 and num_nodes > 0 and reuse.num_nodes == num_nodes and reuse.num_edges == E
+            and reuse.hub_threshold == hub_threshold and reuse.rowptr.device == device and reuse.fingerprint is not None):
+        return _rebuild_csr_if_changed(reuse, src, dst, err_flag)
     rowptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=device)
     col = torch.empty(max(E, 1), dtype=torch.int32, device=device)
     # one small block of device counters, all cleared by the kernels: int64 n_self | int32 hub rows, error | int32 mega rows, slices
@@ -594,12 +625,22 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None, err
     if ws_bytes == 0:
         raise NotImplementedError(f'graphs with {num_nodes} nodes are not supported by the CSR builder')
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    fp = None
+    if fingerprint and not check and E > 0 and num_nodes > 0:
+        fp = torch.zeros(_native.CSR_FINGERPRINT_BYTES, dtype=torch.uint8, device=device)
     with _Span('csr_build', device):
-        _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(n_self_dev),
-                                       hub_threshold, _ptr(hub_rows), _ptr(hub_count), _ptr(mega_rows), _ptr(mega_count), _ptr(err),
-                                       _ptr(ws), ws_bytes, _stream(device)), 'ss_csr_build')
+        if fp is not None:
+            _native.check(lib.ss_csr_build_cached(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(n_self_dev),
+                                                  hub_threshold, _ptr(hub_rows), _ptr(hub_count), _ptr(mega_rows), _ptr(mega_count),
+                                                  _ptr(err), _ptr(ws), ws_bytes, _ptr(fp), _stream(device)), 'ss_csr_build_cached')
+        else:
+            _native.check(lib.ss_csr_build(_ptr(src), _ptr(dst), E, num_nodes, _ptr(rowptr), _ptr(col), _ptr(n_self_dev),
+                                           hub_threshold, _ptr(hub_rows), _ptr(hub_count), _ptr(mega_rows), _ptr(mega_count), _ptr(err),
+                                           _ptr(ws), ws_bytes, _stream(device)), 'ss_csr_build')
     csr = CsrGraph(rowptr, col, num_nodes, n_self_dev, _error_flag(device), hub_rows, hub_count, hub_threshold,
                    mega=(mega_rows, mega_count, mega_scratch))
+    csr.num_edges = E
+    csr.fingerprint = fp  # a later build_csr(..., reuse=csr) compares contents with these sums
     if check:
         # the one synchronising read of strict mode brings the hub / mega row counts along: a graph without such rows
         # (every unskewed graph) then skips both hub-pass launches of every hop (4 us each)
@@ -608,6 +649,12 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None, err
             raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
         csr.has_hub_rows = bool(int(host[2]) or int(host[4]))
     return csr
+
+
+# ELPH.forward builds a fresh self-looped edge_index every step (reference models/elph.py:186): the CSR cache below is keyed on the
+# tensor OBJECT, so that step rebuilt an identical CSR every time.  With this on, a cache miss on a tensor of the cached shape goes
+# through ss_csr_build_cached: one streaming pass over the edges + a device-side comparison; the build only runs if the edges differ.
+REUSE_CSR_BY_CONTENT = os.environ.get('SS_REUSE_CSR', '1') != '0'
 
 
 class _CsrCache(object):
@@ -627,7 +674,10 @@ class _CsrCache(object):
         if self._ref is not None and self._ref() is edge_index and self._version == edge_index._version and self._key == key:
             return self._csr
         check, err_flag = self._check(device, 'sketch propagation (edge_index)')
-        csr = build_csr(edge_index, num_nodes, device, check=check, err_flag=err_flag)
+        # another tensor object (or an edited one) of the SAME shape: the cached CSR's buffers are rebuilt only if the contents
+        # differ, decided on the device (REUSE_CSR_BY_CONTENT; strict builds read their flags back and always rebuild)
+        reuse = self._csr if (REUSE_CSR_BY_CONTENT and self._key == key) else None
+        csr = build_csr(edge_index, num_nodes, device, check=check, err_flag=err_flag, reuse=reuse, fingerprint=REUSE_CSR_BY_CONTENT)
         self._ref, self._version, self._key, self._csr = weakref.ref(edge_index), edge_index._version, key, csr
         return csr
 
@@ -713,6 +763,7 @@ class MinhashPropagation(object):
                         raise RuntimeError('deferred MinHash first hop has no kernel for this shape')
                 lazy = LazyMinhash(out_u32, pending=fill)
                 csr.pending_minhash = (weakref.ref(lazy), perms, P, p)  # the hop-2 hll_prop on this CSR may take it over
+                csr.pending_lazies.append(weakref.ref(lazy))
                 return lazy
             if not _first_hop_from_ids(csr, device, hop0[0], x.size(1), hop0[1], out_u32, None):
                 out_u32 = None
@@ -729,7 +780,9 @@ class MinhashPropagation(object):
                     with _Span('propagate_mh_rows', device):
                         _native.check(_native.lib().ss_minhash_hop_rows(byref(graph), _ptr(mh_in), _ptr(out), mh_in.size(1), _ptr(rows),
                                                                         rows.numel(), _stream(device)), 'ss_minhash_hop_rows')
-                return LazyMinhash(out_u32, pending=fill, partial=fill_rows)
+                lazy = LazyMinhash(out_u32, pending=fill, partial=fill_rows)
+                csr.pending_lazies = [r for r in csr.pending_lazies if r() is not None] + [weakref.ref(lazy)]
+                return lazy
             out_u32, _ = _propagate(csr, mh_in, None, device)
         if LAZY_MINHASH and x.device == device:
             return LazyMinhash(out_u32)
