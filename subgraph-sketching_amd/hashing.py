@@ -411,8 +411,11 @@ class LazyMinhash(torch.Tensor):
             fill, self._pending, self._partial = self._pending, None, None
             fill()
 
+    materialisations = 0  # class-wide count of 8-byte copies made (tests assert that the ELPH call sequence makes none)
+
     def materialise(self):
         if self._real is None:
+            LazyMinhash.materialisations += 1
             self.resolve()
             self._real = unpack_minhash(self._packed)
             self._packed = None
@@ -729,11 +732,14 @@ class MinhashPropagation(object):
     """drop-in for reference hashing.py:28-35: out[i] = min over in-neighbours (edges j -> i) of x[j];
     rows without an in-edge are 0.  x: int64 [N, P] with values in [0, 2^32)."""
 
-    def __init__(self, csr_cache=None, after_host_copy=None):
+    def __init__(self, csr_cache=None, after_host_copy=None, defer_first_hop=None, defer_table_hop=None):
         """after_host_copy: called once a result has been copied back to a CPU caller (the copy has waited for the launches, so
-        the owner's deferred bounds report is final and is raised from the offending call itself)"""
+        the owner's deferred bounds report is final and is raised from the offending call itself).
+        defer_first_hop / defer_table_hop: None = the module defaults DEFER_FIRST_HOP / DEFER_TABLE_HOP (environment overrides
+        SS_FUSED_STAGE / SS_DEFER_TABLE_HOP are for tests and measurements); ElphHashes passes its constructor arguments"""
         self._cache = csr_cache or _default_csr_cache
         self._after_host_copy = after_host_copy
+        self.defer_first_hop, self.defer_table_hop = defer_first_hop, defer_table_hop
 
     def _to_caller(self, out, x, device):
         if x.device == device:
@@ -753,7 +759,8 @@ class MinhashPropagation(object):
         if hop0 is not None and hop0[0] is not None:
             out_u32 = torch.empty((x.size(0), x.size(1)), dtype=torch.int32, device=device)
             P, p = x.size(1), hop0[1]
-            if (DEFER_FIRST_HOP and LAZY_MINHASH and x.device == device and p == 8 and P % 64 == 0 and P <= 256
+            defer_first = DEFER_FIRST_HOP if self.defer_first_hop is None else self.defer_first_hop
+            if (defer_first and LAZY_MINHASH and x.device == device and p == 8 and P % 64 == 0 and P <= 256
                     and x.size(0) * 256 <= ElphHashes.FUSED_STAGE_MAX_TABLE_BYTES):
                 perms = hop0[0]
 
@@ -769,7 +776,7 @@ class MinhashPropagation(object):
                 out_u32 = None
         if out_u32 is None:
             mh_in = _packed_minhash_of(x, device)
-            if DEFER_TABLE_HOP and LAZY_MINHASH and x.device == device:
+            if (DEFER_TABLE_HOP if self.defer_table_hop is None else self.defer_table_hop) and LAZY_MINHASH and x.device == device:
                 out_u32 = torch.empty_like(mh_in)
 
                 def fill(csr=csr, mh_in=mh_in, out=out_u32, device=device):
@@ -861,8 +868,14 @@ class ElphHashes(object):
     # measurement hook
     FUSED_STAGE_MAX_TABLE_BYTES = int(os.environ.get('SS_FUSED_STAGE_MAX_MB', str(1 << 30))) << 20
 
-    def __init__(self, args):
+    def __init__(self, args, fuse_hop_stage=None, defer_first_hop=None, defer_table_hop=None):
+        """args: the reference's namespace (max_hash_hops, floor_sf, minhash_num_perm, hll_p, use_zero_one).  Extensions (keyword
+        only in spirit; None = the engine's defaults): fuse_hop_stage -- hop-1 MinHash + hop-2 HLL in one launch inside
+        build_hash_tables; defer_first_hop / defer_table_hop -- the deferred launches of the ELPH call sequence (minhash_prop
+        records its hop, the next consumer decides how much of it runs).  The environment variables
+        SS_FUSED_STAGE / SS_DEFER_TABLE_HOP only set the defaults (tests, A/B measurements)."""
         assert args.max_hash_hops in {1, 2, 3}, f'hashing is not implemented for {args.max_hash_hops} hops'
+        self._defer_first_hop, self._defer_table_hop = defer_first_hop, defer_table_hop
         self.max_hops = args.max_hash_hops
         self.floor_sf = args.floor_sf  # if true set minimum sf to 0
         # minhash params (reference hashing.py:58-63)
@@ -872,7 +885,7 @@ class ElphHashes(object):
         self.minhash_seed = 1
         self.num_perm = args.minhash_num_perm
         self._csr_cache = _CsrCache(self._bounds)
-        self.minhash_prop = MinhashPropagation(self._csr_cache, self._report_after_host_copy)
+        self.minhash_prop = MinhashPropagation(self._csr_cache, self._report_after_host_copy, defer_first_hop, defer_table_hop)
         # hll params (reference hashing.py:65-81)
         self.p = args.hll_p
         self.m = 1 << self.p
@@ -892,7 +905,7 @@ class ElphHashes(object):
         self._dev_perms = {}
         self.fuse_first_hop = True  # compute hop 1 straight from node ids when the fused kernel supports (num_perm, p)
         # hop-1 MinHash + hop-2 HLL in one launch (ss_fused_hop_stage; num_perm == 128, hll_p == 8, max_hops >= 2, unsharded build)
-        self.fuse_hop_stage = os.environ.get('SS_FUSED_STAGE', '1') != '0'
+        self.fuse_hop_stage = (os.environ.get('SS_FUSED_STAGE', '1') != '0') if fuse_hop_stage is None else bool(fuse_hop_stage)
         # node ids outside [0, num_nodes): 'deferred' (default) = IndexError at the NEXT call into this engine or at
         # check_errors(), no host synchronisation inside a step; True = IndexError from the offending call itself (one
         # synchronising 4-byte read per CSR build / query call); False = never reported (edges dropped, NaN feature rows)
@@ -915,7 +928,8 @@ class ElphHashes(object):
         self.__dict__.update(state)
         self._deferred = _DeferredErrors()
         self._csr_cache = _CsrCache(self._bounds)
-        self.minhash_prop = MinhashPropagation(self._csr_cache, self._report_after_host_copy)
+        self.minhash_prop = MinhashPropagation(self._csr_cache, self._report_after_host_copy, self.__dict__.get('_defer_first_hop'),
+                                               self.__dict__.get('_defer_table_hop'))
         self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m, self._report_after_host_copy)
 
     def _report_after_host_copy(self):
