@@ -214,6 +214,49 @@ def secondary_case(ssa, dev, name, config, graph='uniform', alpha=0.5, api='buil
                if frac and frac > 1.0 else {})}
 
 
+def strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank, reps=3):
+    """after the timed region, N > 1: t(1 GPU) and t(N GPUs) of the same two jobs, max over ranks; see the call site"""
+    nf = h * (h + 2)
+    L = min(cfg['buddy_links'], 64 * batch)
+    links_all = torch.from_numpy(synthetic_links(n, L, 2)).to(dev)  # the SAME link set on every rank
+    exchange = ssa.dist.choose_exchange(dev)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e3
+
+    def job(links, build, sharded_query):
+        table, cards = build()
+        if sharded_query:
+            return ssa.dist.sharded_subgraph_features(lambda lk: eh.get_subgraph_features(lk, table, cards), links)
+        return eh.get_subgraph_features(links, table, cards)
+
+    replicated = lambda: eh.build_hash_tables(n, ei)
+    sharded = lambda: ssa.dist.sharded_build_hash_tables(eh, n, ei)
+    res = {'exchange': exchange, 'exchange_probe_seconds': ssa.dist.exchange_probe_times(dev), 'world': world}
+    for name, links in (('buddy_precompute', links_all), ('build_plus_one_global_batch', links_all[:batch])):
+        t1 = timed(lambda: job(links, replicated, False))
+        row = {'pairs': links.size(0), 'ms_1gpu_same_work': t1}
+        for bname, build in (('replicated_build', replicated), ('sharded_build', sharded)):
+            tn = timed(lambda: job(links, build, True))
+            row[bname] = {'ms': tn, 'speedup_vs_n1_same_work': t1 / tn, 'pairs_per_s': links.size(0) / (tn * 1e-3)}
+        res[name] = row
+    res['note'] = ('same job on 1 GPU (every rank runs all of it, no communication) vs sharded over the ranks: links cut into contiguous '
+                   'slices, feature rows all-gathered; build replicated on every rank or destination rows sharded with an in-place exchange '
+                   'per hop and sketch.  At ogbl-collab size the build is 0.4 ms and the exchange costs more than it saves (DESIGN 6); '
+                   '--config ppa / citation2 --scaling strong --build sharded are the shapes it is for.')
+    return res
+
+
 SECONDARY = [
     # (name, config, graph, alpha, api, batch): BASELINE configs[3] / [4] as SURVEY 8(d) asks -- U and PL at the same N, E --,
     # configs[2] (the ELPH message-passing step at the reference's batch size), BUDDY's precompute at collab size
@@ -255,6 +298,7 @@ def main():
                          'across ranks + in-place all-gather after every hop (pays off at ogbl-ppa / citation2 sizes)')
     ap.add_argument('--sustain-seconds', type=float, default=8.0,
                     help='length of the sustained run after the timed region (0 = skip); long enough for a 5 s utilisation sampler')
+    ap.add_argument('--no-strong', action='store_true', help='N > 1: skip the strong-scaling figures measured after the timed region')
     ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` shapes measured after the timed region')
     ap.add_argument('--no-kernel-table', action='store_true', help='skip the per-kernel HIP-event table (extra steps after the timed region)')
     a = ap.parse_args()
@@ -268,12 +312,20 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    # test hooks (tools/two_ranks_one_gpu.sh: the N > 1 control flow on a one-GPU box): every rank on device 0, gloo instead of RCCL
+    one_device = os.environ.get('SS_BENCH_SINGLE_DEVICE') == '1'
+    backend = os.environ.get('SS_BENCH_BACKEND', 'nccl')
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if launched:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {a.gpus}'
 
     import subgraph_sketching_amd as ssa
@@ -502,6 +554,16 @@ def main():
                                      if world > 1 else 'single GPU: nothing is repeated')
     if kernel_table:
         out['kernels'] = kernel_table
+    # ---- N > 1: strong-scaling figures beside the weak line -----------------------------------------------------
+    # The timed region above is weak scaling with a replicated build: ~N x by construction.  Here the SAME job is timed on one GPU
+    # (every rank runs all of it, no communication) and sharded over the N ranks, for the two jobs BASELINE names: the BUDDY
+    # precompute of the config (one build + its link set) and one build + one global batch; with the build replicated and
+    # row-sharded (exchange form chosen by dist.choose_exchange's micro-probe).  speedup_vs_n1_same_work = t(1 GPU) / t(N GPUs).
+    if launched and world > 1 and a.api == 'build_query' and not a.no_strong:
+        try:
+            out['strong'] = strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank)
+        except Exception as exc:  # (deterministic failures are the same on every rank; the headline line must survive)
+            out['strong'] = {'error': f'{type(exc).__name__}: {exc}'}
     default_line = a.config == 'collab' and a.graph == 'uniform' and a.api == 'build_query' and batch == cfg['batch']
     feats_host = feats.cpu().numpy() if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
     if rank == 0 and world == 1 and not a.no_secondary and default_line:

@@ -39,8 +39,18 @@ def sharded_subgraph_features(compute, links, group=None):
     padded = local.new_zeros((per, F))
     padded[:hi - lo] = local
     gathered = local.new_empty((world * per, F))
-    dist.all_gather_into_tensor(gathered, padded.contiguous(), group=group)
+    _all_gather_rows(gathered, padded.contiguous(), group)
     return gathered[:L]
+
+
+def _all_gather_rows(dst, src, group=None, async_op=False):
+    """all_gather_into_tensor; backends without device collectives (gloo in the one-GPU tests) go through the host"""
+    if not dst.is_cuda or dist.get_backend(group) == 'nccl':
+        return dist.all_gather_into_tensor(dst, src, group=group, async_op=async_op)
+    staged = torch.empty(dst.shape, dtype=dst.dtype, device='cpu')
+    dist.all_gather_into_tensor(staged, src.cpu(), group=group)
+    dst.copy_(staged)
+    return None
 
 
 def exchange_blocks_p2p(full, rank, world, per, group=None):
@@ -63,6 +73,61 @@ def exchange_blocks_p2p(full, rank, world, per, group=None):
     return reqs
 
 
+_EXCHANGE_CHOICE = {}
+
+
+def choose_exchange(device, group=None, block_bytes=32 << 20, reps=3):
+    """which form of the per-hop block exchange is faster on THIS node, measured once per (process, group): the collective
+    (`all_gather_into_tensor`) or world - 1 concurrent point-to-point transfers per rank (one per xGMI link; a ring all-gather is
+    bound by ONE link).  Every rank times both on a block of `block_bytes` per rank, the MAX over ranks decides (all ranks agree by
+    construction).  SS_EXCHANGE=all_gather|p2p forces a form (tests, A/B runs).  Returns 'all_gather' or 'p2p'."""
+    forced = os.environ.get('SS_EXCHANGE')
+    if forced in ('all_gather', 'p2p'):
+        return forced
+    key = (str(device), id(group))
+    if key in _EXCHANGE_CHOICE:
+        return _EXCHANGE_CHOICE[key]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    choice = 'all_gather'
+    if world > 1:
+        import time
+        per = max(block_bytes // 4, 1)
+        full = torch.zeros(world * per, dtype=torch.int32, device=device)
+        cuda = torch.device(device).type == 'cuda'
+
+        def sync():
+            if cuda:
+                torch.cuda.synchronize(device)
+
+        def run(form):
+            mine = full[rank * per:(rank + 1) * per]
+            if form == 'p2p':
+                exchange_blocks_p2p(full, rank, world, per, group)
+            else:
+                dist.all_gather_into_tensor(full, mine if cuda else mine.clone(), group=group)
+            sync()
+        times = {}
+        for form in ('all_gather', 'p2p'):
+            run(form)  # warm-up (connection set-up)
+            dist.barrier(group=group)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run(form)
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            times[form] = float(t.item())
+        choice = 'p2p' if times['p2p'] < 0.9 * times['all_gather'] else 'all_gather'
+        _EXCHANGE_CHOICE[(key, 'times')] = {k: v / reps for k, v in times.items()}
+    _EXCHANGE_CHOICE[key] = choice
+    return choice
+
+
+def exchange_probe_times(device, group=None):
+    """seconds per exchange of the probe block for both forms (None before choose_exchange ran or when a form was forced)"""
+    return _EXCHANGE_CHOICE.get(((str(device), id(group)), 'times'))
+
+
 class RowShard(object):
     """destination-row partition of one build across the ranks of `group` + the exchange that follows every hop.
 
@@ -73,7 +138,9 @@ class RowShard(object):
     gather is asynchronous (its own stream): `ElphHashes._build` overlaps the MinHash exchange with the HLL kernel and
     vice versa.  Other backends (gloo in the tests) stage device tensors through the host."""
 
-    def __init__(self, num_nodes, group=None):
+    def __init__(self, num_nodes, group=None, exchange=None):
+        """exchange: 'all_gather' | 'p2p' | None (= SS_EXCHANGE if set, else the collective; sharded_build_hash_tables passes the
+        form choose_exchange measured)"""
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.per = max((num_nodes + self.world - 1) // self.world, 1)
@@ -83,7 +150,7 @@ class RowShard(object):
         self.native = dist.get_backend(group) == 'nccl'
         # SS_EXCHANGE=p2p: G - 1 concurrent point-to-point transfers per rank instead of one all_gather (tools/probe_allgather.py
         # decides which is faster on a given node: a ring all-gather is bound by one xGMI link)
-        self.p2p = os.environ.get('SS_EXCHANGE', 'all_gather') == 'p2p'
+        self.p2p = (exchange or os.environ.get('SS_EXCHANGE', 'all_gather')) == 'p2p'
 
     def block(self, full):
         return full[self.rank * self.per:(self.rank + 1) * self.per]
@@ -115,7 +182,9 @@ def sharded_build_hash_tables(eh, num_nodes, edge_index, group=None):
     the rank that owns it with the same arithmetic)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return eh.build_hash_tables(num_nodes, edge_index)
-    return eh._build(num_nodes, edge_index, RowShard(num_nodes, group))
+    device = edge_index.device if edge_index.is_cuda else (torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else edge_index.device)
+    exchange = choose_exchange(device, group) if dist.get_backend(group) == 'nccl' else None  # (a startup micro-probe, not an env var)
+    return eh._build(num_nodes, edge_index, RowShard(num_nodes, group, exchange))
 
 
 # ---- workload bookkeeping shared by bench.py and the gloo tests ------------------------------------------------------
@@ -188,7 +257,11 @@ class AsyncFeatureGather(object):
             self.pad[slot][:feats.size(0)].copy_(feats)
             src = self.pad[slot]
         dst = self.out[slot]
-        work = dist.all_gather_into_tensor(dst, src.contiguous(), group=self.group, async_op=True)
+        work = _all_gather_rows(dst, src.contiguous(), self.group, async_op=True)
+        if work is None:  # (host-staged: already complete)
+            self.issued += 1
+            self.slot_work[slot] = None
+            return dst
         self.works.append((work, src))
         self.slot_work[slot] = work
         self.issued += 1

@@ -128,7 +128,7 @@ def test_row_shard_bounds():
             assert covered[0][0] == 0 and covered[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
             assert per * world >= n
-    assert ssa.dist.RowShard.__init__.__code__.co_argcount == 3
+    assert ssa.dist.RowShard.__init__.__code__.co_argcount == 4  # (self, num_nodes, group, exchange)
 
 
 # ---- bench.py's workload bookkeeping: BatchPlan + AsyncFeatureGather under both scaling modes -------------------------
@@ -220,3 +220,30 @@ def _p2p_subgroup_worker(rank, world, port, per):
 def test_point_to_point_block_exchange_in_a_sub_group():
     """P2POp peers are global ranks; a per-node sub-group must exchange with its own members"""
     mp.spawn(_p2p_subgroup_worker, args=(4, _free_port(), 5), nprocs=4, join=True)
+
+
+def _probe_worker(rank, world, port):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.pop('SS_EXCHANGE', None)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import subgraph_sketching_amd as ssa
+    choice = ssa.dist.choose_exchange(torch.device('cpu'), None, block_bytes=1 << 16, reps=2)
+    times = ssa.dist.exchange_probe_times(torch.device('cpu'))
+    assert choice in ('all_gather', 'p2p') and set(times) == {'all_gather', 'p2p'} and all(t > 0 for t in times.values())
+    # every rank reaches the same decision (it is taken on the max over ranks) and the decision is cached
+    picks = [None] * world
+    dist.all_gather_object(picks, choice)
+    assert len(set(picks)) == 1 and ssa.dist.choose_exchange(torch.device('cpu')) == choice
+    shard = ssa.dist.RowShard(100, None, choice)
+    assert shard.p2p == (choice == 'p2p')
+    os.environ['SS_EXCHANGE'] = 'p2p'   # the environment variable is an override for tests / A-B runs
+    assert ssa.dist.choose_exchange(torch.device('cpu')) == 'p2p'
+    dist.destroy_process_group()
+
+
+def test_exchange_form_is_chosen_by_a_micro_probe():
+    """the form of the per-hop block exchange (collective or world - 1 point-to-point transfers) is measured at
+    start-up, the same on every rank; SS_EXCHANGE only overrides"""
+    mp.spawn(_probe_worker, args=(3, _free_port()), nprocs=3, join=True)
