@@ -242,11 +242,17 @@ def strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank
 
     replicated = lambda: eh.build_hash_tables(n, ei)
     sharded = lambda: ssa.dist.sharded_build_hash_tables(eh, n, ei)
+    builds = [('replicated_build', replicated), ('sharded_build', sharded)]
     res = {'exchange': exchange, 'exchange_probe_seconds': ssa.dist.exchange_probe_times(dev), 'world': world}
+    try:  # peer-write: needs the ranks to map each other's tables (CUDA-IPC); its constructor fails on every rank or on none
+        shard = ssa.dist.PeerShard(n, eh.max_hops, eh.num_perm, eh.m, dev)
+        builds.append(('peer_write_build', lambda: ssa.dist.peer_write_build_hash_tables(eh, n, ei, shard=shard)[:2]))
+    except Exception as exc:
+        res['peer_write_build_unavailable'] = f'{type(exc).__name__}: {exc}'
     for name, links in (('buddy_precompute', links_all), ('build_plus_one_global_batch', links_all[:batch])):
         t1 = timed(lambda: job(links, replicated, False))
         row = {'pairs': links.size(0), 'ms_1gpu_same_work': t1}
-        for bname, build in (('replicated_build', replicated), ('sharded_build', sharded)):
+        for bname, build in builds:
             tn = timed(lambda: job(links, build, True))
             row[bname] = {'ms': tn, 'speedup_vs_n1_same_work': t1 / tn, 'pairs_per_s': links.size(0) / (tn * 1e-3)}
         res[name] = row
@@ -293,9 +299,10 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='N > 1. weak (default): every rank its own batch, replicated build (N x by construction); strong: one '
                          'global batch / link set sharded across the ranks (BASELINE configs[3], [4])')
-    ap.add_argument('--build', default='replicated', choices=['replicated', 'sharded'],
+    ap.add_argument('--build', default='replicated', choices=['replicated', 'sharded', 'peer'],
                     help='N > 1 only. replicated (default): every rank builds the whole table; sharded: destination rows split '
-                         'across ranks + in-place all-gather after every hop (pays off at ogbl-ppa / citation2 sizes)')
+                         'across ranks + in-place all-gather after every hop (pays off at ogbl-ppa / citation2 sizes); peer: the same row split, '
+                         'every rank\'s kernels store their rows straight into all ranks\' (IPC-mapped) tables: no exchange step')
     ap.add_argument('--sustain-seconds', type=float, default=8.0,
                     help='length of the sustained run after the timed region (0 = skip); long enough for a 5 s utilisation sampler')
     ap.add_argument('--no-strong', action='store_true', help='N > 1: skip the strong-scaling figures measured after the timed region')
@@ -350,9 +357,13 @@ def main():
     ei = torch.from_numpy(ei_np).to(dev)
     links = plan.local(torch.from_numpy(links_np).to(dev)).contiguous()
     gather = ssa.dist.AsyncFeatureGather(plan, nf, dev) if launched else (lambda f: f)
-    sharded_build = launched and world > 1 and a.build == 'sharded'
+    sharded_build = launched and world > 1 and a.build in ('sharded', 'peer')
+    peer_state = {'shard': None}
 
     def build_tables():
+        if sharded_build and a.build == 'peer':
+            table, cards, peer_state['shard'] = ssa.dist.peer_write_build_hash_tables(eh, n, ei, shard=peer_state['shard'])
+            return table, cards
         if sharded_build:
             return ssa.dist.sharded_build_hash_tables(eh, n, ei)
         return eh.build_hash_tables(n, ei)
@@ -514,7 +525,7 @@ def main():
                    'num_nodes': n, 'directed_edges': e_dir, 'max_hash_hops': h, 'minhash_num_perm': P, 'hll_p': HLL_P,
                    'pairs_per_step_per_gpu': links.size(0), 'global_pairs_per_step': pairs_per_step,
                    'parallelism': (f'edge batches sharded x{world} ({a.scaling} scaling), all_gather of features; sketch table ' +
-                                   (f'built row-sharded x{world} with an in-place all_gather per hop and sketch' if sharded_build
+                                   ((f'built row-sharded x{world}, every rank writing its rows into all ranks\' tables (peer-write, no exchange step)' if a.build == 'peer' else f'built row-sharded x{world} with an in-place all_gather per hop and sketch') if sharded_build
                                     else 'replicated (every rank builds it)')),
                    'hll_tables': eh.tables_id},
         'roofline': {'kernel': roof_kernel + ('' if h > 1 else ' (not launched at h=1)') +

@@ -92,7 +92,18 @@ typedef struct ss_csr_graph {
     int64_t row_begin;                /* destination rows [row_begin, row_end) are computed by ss_propagate /    */
     int64_t row_end;                  /* ss_first_hop (multi-GPU destination-range sharding);       */
                                       /* row_end == 0 means all rows.  Outputs are indexed by the GLOBAL row id.  */
+    /* Peer-write build (the row-sharded build without an exchange step): every row a launch finishes is ALSO    */
+    /* stored into these tables of the other ranks (device pointers into peers' memory, mapped through hipIpc / torch's       */
+    /* CUDA-IPC; same shapes and strides as the launch's own mh_out / hll_out / cards_out; entries of a sketch the launch does */
+    /* not produce are ignored).  The stores travel over xGMI while the kernel runs; the hop boundary then needs a cross-rank   */
+    /* barrier only.  n_mirrors == 0: none.                                                                                   */
+    int32_t n_mirrors;
+    int32_t reserved2;
+    uint32_t *mirror_mh[7];           /* SS_MAX_MIRRORS */
+    uint8_t *mirror_hll[7];
+    float *mirror_cards[7];
 } ss_csr_graph;
+#define SS_MAX_MIRRORS 7
 
 /* CSR-by-destination of an edge list.  Replaces the message materialisation of
  * torch_geometric MessagePassing.propagate as used by hashing.py:34,44 (flow source -> target).

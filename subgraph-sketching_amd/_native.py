@@ -28,12 +28,14 @@ class CsrGraphStruct(ctypes.Structure):
     _fields_ = [('rowptr', c_void_p), ('col', c_void_p), ('num_nodes', c_int64), ('n_self_loops', c_int64),
                 ('n_self_loops_dev', c_void_p), ('hub_threshold', c_int32), ('reserved', c_int32),
                 ('hub_rows', c_void_p), ('hub_count', c_void_p), ('mega_rows', c_void_p), ('mega_count', c_void_p),
-                ('mega_scratch', c_void_p), ('row_begin', c_int64), ('row_end', c_int64)]
+                ('mega_scratch', c_void_p), ('row_begin', c_int64), ('row_end', c_int64),
+                ('n_mirrors', c_int32), ('reserved2', c_int32), ('mirror_mh', c_void_p * 7), ('mirror_hll', c_void_p * 7),
+                ('mirror_cards', c_void_p * 7)]
 
 
-ABI_VERSION = 124  # ss_version() of the library this module's struct mirrors and signatures describe
+ABI_VERSION = 125  # ss_version() of the library this module's struct mirrors and signatures describe
 PROF_MINHASH_HOP, PROF_HLL_HOP, PROF_FIRST_HOP_MH, PROF_FIRST_HOP_HLL, PROF_PAIRS, PROF_CSR, PROF_HUB, PROF_FUSED, PROF_MINHASH_ROWS = range(9)  # SS_PROF_* tags
-MEGA_SLICE, MEGA_SLOT_BYTES, CSR_FINGERPRINT_BYTES = 1024, 1280, 8448  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
+MEGA_SLICE, MEGA_SLOT_BYTES, CSR_FINGERPRINT_BYTES, MAX_MIRRORS = 1024, 1280, 8448, 7  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/subgraph_sketch.h and include/subgraph_sketch_debug.h

@@ -257,6 +257,14 @@ __device__ __forceinline__ void publish_drain() { asm volatile("s_waitcnt vmcnt(
 __device__ __forceinline__ int take_ticket(int32_t *counter) { return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void reset_ticket(int32_t *counter) { __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// tables of the other ranks that receive every finished row as well (ss_csr_graph.mirror_*)
+struct Mirrors {
+    int n;
+    uint32_t *mh[SS_MAX_MIRRORS];
+    uint8_t *hll[SS_MAX_MIRRORS];
+    float *cards[SS_MAX_MIRRORS];
+};
+
 struct GraphArgs {  // device-side view of ss_csr_graph
     const int64_t *rowptr;
     const int32_t *col;
@@ -274,6 +282,7 @@ struct GraphArgs {  // device-side view of ss_csr_graph
     // out-of-range ids ignored, duplicates harmless); nullptr for every other launch
     const int64_t *row_list = nullptr;
     int64_t n_list = 0;
+    Mirrors mir = {};
     __host__ __device__ int64_t rows() const { return row1 - row0; }
     __device__ bool owns(int64_t i) const { return i >= row0 && i < row1; }
 };
@@ -282,9 +291,39 @@ inline GraphArgs to_args(const ss_csr_graph &g)
 {
     const bool all = g.row_end == 0 && g.row_begin == 0;
     const bool mega = g.mega_rows && g.mega_count && g.mega_scratch;
-    return GraphArgs{g.rowptr, g.col, g.num_nodes, g.n_self_loops, g.n_self_loops_dev, g.hub_threshold, g.hub_rows, g.hub_count,
-                     mega ? const_cast<int32_t *>(g.mega_rows) : nullptr, mega ? g.mega_count : nullptr,
-                     mega ? static_cast<uint8_t *>(g.mega_scratch) : nullptr, all ? 0 : g.row_begin, all ? g.num_nodes : g.row_end};
+    GraphArgs a{g.rowptr, g.col, g.num_nodes, g.n_self_loops, g.n_self_loops_dev, g.hub_threshold, g.hub_rows, g.hub_count,
+                mega ? const_cast<int32_t *>(g.mega_rows) : nullptr, mega ? g.mega_count : nullptr,
+                mega ? static_cast<uint8_t *>(g.mega_scratch) : nullptr, all ? 0 : g.row_begin, all ? g.num_nodes : g.row_end};
+    a.mir.n = g.n_mirrors > 0 && g.n_mirrors <= SS_MAX_MIRRORS ? g.n_mirrors : 0;
+    for (int m = 0; m < a.mir.n; ++m) {
+        a.mir.mh[m] = g.mirror_mh[m];
+        a.mir.hll[m] = g.mirror_hll[m];
+        a.mir.cards[m] = g.mirror_cards[m];
+    }
+    return a;
+}
+
+// a finished piece of a row also goes to the peers' tables (same element offset; a launch that does not produce a sketch never
+// calls that sketch's helper, so its mirror entries may be null)
+__device__ __forceinline__ void mirror_mh4(const Mirrors &mir, int64_t off, u32x4 v)
+{
+    for (int m = 0; m < mir.n; ++m) *reinterpret_cast<u32x4 *>(mir.mh[m] + off) = v;
+}
+__device__ __forceinline__ void mirror_mh1(const Mirrors &mir, int64_t off, uint32_t v)
+{
+    for (int m = 0; m < mir.n; ++m) mir.mh[m][off] = v;
+}
+__device__ __forceinline__ void mirror_hll16(const Mirrors &mir, int64_t off, u32x4 v)
+{
+    for (int m = 0; m < mir.n; ++m) *reinterpret_cast<u32x4 *>(mir.hll[m] + off) = v;
+}
+__device__ __forceinline__ void mirror_hll4(const Mirrors &mir, int64_t off, uint32_t v)
+{
+    for (int m = 0; m < mir.n; ++m) *reinterpret_cast<uint32_t *>(mir.hll[m] + off) = v;
+}
+__device__ __forceinline__ void mirror_card(const Mirrors &mir, int64_t off, float v)
+{
+    for (int m = 0; m < mir.n; ++m) mir.cards[m][off] = v;
 }
 
 // optional HIP-event bracket around a launch (ss_debug.hip; a no-op unless ss_profile_enable selected `tag`)

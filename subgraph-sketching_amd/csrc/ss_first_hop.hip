@@ -80,13 +80,17 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
             for (int q = 0; q < PPL; ++q) acc[q] = 0u;  // no in-edge, no self loop: all-zero row (PyG default)
         }
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = acc[q];
+        for (int q = 0; q < PPL; ++q) {
+            mh_out[i * P + lane + kWave * q] = acc[q];
+            mirror_mh1(g.mir, i * P + lane + kWave * q, acc[q]);
+        }
     }
     if (!DO_HLL) return;
     // the wave's LDS row is only touched by this wave: a wave-level fence orders the atomics before the read
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint32_t regs = pack_hll_quad(my_row, lane);  // HLL registers 4*lane .. 4*lane+3
     *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
+    mirror_hll4(g.mir, i * 256 + 4 * lane, regs);
 
     if (want_cards) {
         int nonzero = 0;
@@ -96,7 +100,11 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
             nonzero += __shfl_xor(nonzero, off);
             hsum += __shfl_xor(hsum, off);
         }
-        if (lane == 0) cards_out[i * cards_stride] = hll_estimate(est, 256 - nonzero, hsum);
+        if (lane == 0) {
+            const float card = hll_estimate(est, 256 - nonzero, hsum);
+            cards_out[i * cards_stride] = card;
+            mirror_card(g.mir, i * cards_stride, card);
+        }
     }
 }
 
@@ -115,12 +123,12 @@ __global__ __launch_bounds__(256) void first_hop_kernel(GraphArgs g, const uint6
 // (The walk itself is MinhashRows of ss_walks.hpp, shared with the fused kernel of ss_fused_hop.hip.)
 constexpr int kRowsPerWave = 8;
 
-template <int PPL, int R>
+template <int PPL, int R, bool MIR>
 __global__ __launch_bounds__(256) void first_hop_rows_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
                                                              uint32_t *__restrict__ mh_out, int p, bool skip_hubs)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    MinhashRows<PPL, R> m;
+    MinhashRows<PPL, R, MIR> m;
     if (!m.init(g, g.row0 + ((int64_t)blockIdx.x * (blockDim.x / kWave) + wave) * R, pa, pb, p, skip_hubs)) return;
     for (int r = 0; r < m.rows; ++r) m.row(r, mh_out);  // wave-uniform
 }
@@ -205,7 +213,12 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
         }
         if (ok && !hub) {
             *reinterpret_cast<u32x4 *>(hll_out + i * 256 + 16 * l) = packed;
-            if (want_cards && l == 0) cards_out[i * cards_stride] = hll_estimate(est, 256 - nonzero, hsum);
+            mirror_hll16(g.mir, i * 256 + 16 * l, packed);
+            if (want_cards && l == 0) {
+                const float card = hll_estimate(est, 256 - nonzero, hsum);
+                cards_out[i * cards_stride] = card;
+                mirror_card(g.mir, i * cards_stride, card);
+            }
         }
     }
 }
@@ -274,9 +287,15 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
     auto finish = [&](int64_t i, const uint32_t (&mh)[PPL], uint32_t regs) {
         if (DO_MH) {
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = mh[q];
+            for (int q = 0; q < PPL; ++q) {
+                mh_out[i * P + lane + kWave * q] = mh[q];
+                mirror_mh1(g.mir, i * P + lane + kWave * q, mh[q]);
+            }
         }
-        if (DO_HLL) *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
+        if (DO_HLL) {
+            *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
+            mirror_hll4(g.mir, i * 256 + 4 * lane, regs);
+        }
         if (want_cards) {
             int nonzero = 0;
             float hsum = 0.0f;
@@ -285,7 +304,11 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
                 nonzero += __shfl_xor(nonzero, off);
                 hsum += __shfl_xor(hsum, off);
             }
-            if (lane == 0) cards_out[i * cards_stride] = hll_estimate(est, 256 - nonzero, hsum);
+            if (lane == 0) {
+                const float card = hll_estimate(est, 256 - nonzero, hsum);
+                cards_out[i * cards_stride] = card;
+                mirror_card(g.mir, i * cards_stride, card);
+            }
         }
     };
 
@@ -429,8 +452,11 @@ void launch_minhash_rows(const GraphArgs &g, const uint64_t *a, const uint64_t *
     auto go = [&](auto rows_tag) {
         constexpr int R = decltype(rows_tag)::value;
         constexpr int rows_per_block = 4 * R;
-        hipLaunchKernelGGL((first_hop_rows_kernel<PPL, R>), dim3((unsigned)((g.rows() + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s,
-                           g, a, b, mh_out, p, hubs);
+        const dim3 grid((unsigned)((g.rows() + rows_per_block - 1) / rows_per_block));
+        if (g.mir.n > 0)
+            hipLaunchKernelGGL((first_hop_rows_kernel<PPL, R, true>), grid, dim3(256), 0, s, g, a, b, mh_out, p, hubs);
+        else
+            hipLaunchKernelGGL((first_hop_rows_kernel<PPL, R, false>), grid, dim3(256), 0, s, g, a, b, mh_out, p, hubs);
     };
     if (rows_env == 4) go(std::integral_constant<int, 4>{});
     else if (rows_env == 16) go(std::integral_constant<int, 16>{});

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, 
             }
         }
         const u32x4 acc = hll_acc_result(ae, ao);
-        hll_row16_finish(h.i, h.write, h.nb, h.deg, h.total, acc, kHllInFlight + kHllLds, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c);
+        hll_row16_finish<false>(h.i, h.write, h.nb, h.deg, h.total, acc, kHllInFlight + kHllLds, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c, Mirrors{});  // (the fused stage is the unsharded build's: no peers)
         rp_cur = rp_next;
         rp_next = rp_after;
         ids_cur = ids_next;

@@ -66,7 +66,10 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
             else if (act) acc = minhash_walk(mh_in, nb, deg, total, i, sg, G, P, c);
             for (int off = SG; off < kWave; off <<= 1) acc = min4(acc, shfl_xor4(acc, off));
             if (total == 0) acc = u32x4{0u, 0u, 0u, 0u};
-            if (act && sg == 0) *reinterpret_cast<u32x4 *>(mh_out + i * P + 4 * c) = acc;
+            if (act && sg == 0) {
+                *reinterpret_cast<u32x4 *>(mh_out + i * P + 4 * c) = acc;
+                mirror_mh4(g.mir, i * P + 4 * c, acc);
+            }
         }
     }
 
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
             for (int off = SG; off < kWave; off <<= 1) acc = bytemax16(acc, shfl_xor4(acc, off));
             if (act && sg == 0) {
                 *reinterpret_cast<u32x4 *>(hll_out + i * M + 16 * c) = acc;
+                mirror_hll16(g.mir, i * M + 16 * c, acc);
                 if (want_cards) {
                     hll_dword_stats(acc.x, nonzero, hsum);
                     hll_dword_stats(acc.y, nonzero, hsum);
@@ -105,7 +109,11 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
                     hsum += __shfl_xor(hsum, off);
                 }
             }
-            if (lane == 0) cards_out[i * cards_stride] = hll_estimate(est, M - nonzero, hsum);
+            if (lane == 0) {
+                const float card = hll_estimate(est, M - nonzero, hsum);
+                cards_out[i * cards_stride] = card;
+                mirror_card(g.mir, i * cards_stride, card);
+            }
         }
     }
 }
@@ -207,10 +215,14 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
     };
     // wave 0 stores the finished row (+ its cardinality)
     auto finish = [&](int64_t i, u32x4 mh_acc, u32x4 hll_acc) {
-        if (mh_out && lane < CM) *reinterpret_cast<u32x4 *>(mh_out + i * P + 4 * lane) = mh_acc;
+        if (mh_out && lane < CM) {
+            *reinterpret_cast<u32x4 *>(mh_out + i * P + 4 * lane) = mh_acc;
+            mirror_mh4(g.mir, i * P + 4 * lane, mh_acc);
+        }
         if (hll_out && lane >= 32 && lane < 32 + CH) {  // lanes 32..47 = one DPP row
             const int c = lane - 32;
             *reinterpret_cast<u32x4 *>(hll_out + i * M + 16 * c) = hll_acc;
+            mirror_hll16(g.mir, i * M + 16 * c, hll_acc);
             if (want_cards) {
                 int nonzero = 0;
                 float hsum = 0.0f;
@@ -220,7 +232,11 @@ __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g,
                 hll_dword_stats(hll_acc.w, nonzero, hsum);
                 nonzero = row16_sum_i(nonzero);
                 hsum = row16_sum_f(hsum);
-                if (c == 0) cards_out[i * cards_stride] = hll_estimate(est, M - nonzero, hsum);
+                if (c == 0) {
+                    const float card = hll_estimate(est, M - nonzero, hsum);
+                    cards_out[i * cards_stride] = card;
+                    mirror_card(g.mir, i * cards_stride, card);
+                }
             }
         }
     };

@@ -339,11 +339,14 @@ __device__ __forceinline__ bool first_hop_minhash_fast(const int32_t *__restrict
 // row r is slot 64 - R + r of whatever batch is current; row(r) walks row r over its slice of the batch(es) with the
 // two-phase evaluation (first_hop_minhash_fast above), evaluates the winner exactly and stores the row.  Rows flagged
 // ambiguous (and rows that list themselves: duplicates of the implicit self loop) are redone by the exact walk.
-template <int PPL, int R>
+// MIR: rows also go to the peers' tables (peer-write build); a compile-time switch -- the store loop and the pointer it needs
+// cost first_hop_rows_kernel 14 registers and fused_hop_persistent_kernel its fourth wavefront per SIMD
+template <int PPL, int R, bool MIR = false>
 struct MinhashRows {
     static constexpr int P = PPL * kWave;
     static constexpr int kNb = kWave - R;  // col entries per batch
     int lane, rows, rel, c_n, base, p, hub_threshold;
+    const Mirrors *mir;  // peers' tables (kernel-argument memory: the pointer stays valid for the kernel's lifetime)
     bool skip_hubs;
     int64_t i0, n_self, nid;
     const int32_t *nb;
@@ -367,6 +370,7 @@ struct MinhashRows {
         p = p_;
         skip_hubs = skip;
         hub_threshold = g.hub_threshold;
+        mir = MIR ? &g.mir : nullptr;
     }
 
     // rows [first_row, first_row + n_rows) become the current chunk; rp: lane l holds rowptr[first_row + l] (l <= n_rows)
@@ -495,7 +499,10 @@ struct MinhashRows {
             first_hop_walk<PPL, true, false>(nb + p0, deg, deg + (self ? 1 : 0), i, 0, 1, p, a, b, acc, nullptr, lane);
         }
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) mh_out[i * P + lane + kWave * q] = acc[q];
+        for (int q = 0; q < PPL; ++q) {
+            mh_out[i * P + lane + kWave * q] = acc[q];
+            if constexpr (MIR) mirror_mh1(*mir, i * P + lane + kWave * q, acc[q]);
+        }
     }
 };
 
@@ -503,10 +510,11 @@ struct MinhashRows {
 // group per row, lane c = chunk c): the rest of rows up to kSolo neighbours by their own group, what is left of longer rows
 // by all four groups together, then the row's statistics, its store and its cardinality.  `total` = 0 marks a group without
 // a row to write (past the end, or a hub row left to the hub pass).
+template <bool MIR = true>
 __device__ __forceinline__ void hll_row16_finish(int64_t i, bool write, const int32_t *__restrict__ nb, int deg, int total, u32x4 acc,
                                                  int walked, const uint8_t *__restrict__ hll_in, uint8_t *__restrict__ hll_out,
                                                  float *__restrict__ cards_out, int64_t cards_stride, const EstimatorTables &est,
-                                                 bool want_cards, int c /* lane & 15 */)
+                                                 bool want_cards, int c /* lane & 15 */, const Mirrors &mir)
 {
     constexpr int M = 256;
     // every lane group walks the first kSolo neighbours of its own row; what is left of longer rows is walked by the whole
@@ -544,7 +552,16 @@ __device__ __forceinline__ void hll_row16_finish(int64_t i, bool write, const in
     }
     if (write) {
         *reinterpret_cast<u32x4 *>(hll_out + i * M + 16 * c) = acc;
-        if (want_cards && c == 0) cards_out[i * cards_stride] = hll_estimate(est, M - nonzero, hsum);
+        if constexpr (MIR) mirror_hll16(mir, i * M + 16 * c, acc);
+        if constexpr (MIR) {
+            if (want_cards && c == 0) {
+                const float card = hll_estimate(est, M - nonzero, hsum);
+                cards_out[i * cards_stride] = card;
+                mirror_card(mir, i * cards_stride, card);
+            }
+        } else {
+            if (want_cards && c == 0) cards_out[i * cards_stride] = hll_estimate(est, M - nonzero, hsum);
+        }
     }
 }
 
@@ -565,7 +582,7 @@ __device__ __forceinline__ void hll_hop_row16(const GraphArgs &g, int64_t row, b
     const int total = (!ok || hub) ? 0 : deg + (i < n_self ? 1 : 0);
     const int32_t *nb = g.col + rb;
     const u32x4 acc = hll_walk_first16(hll_in, nb, deg, total, i, c);
-    hll_row16_finish(i, ok && !hub, nb, deg, total, acc, 16, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c);
+    hll_row16_finish(i, ok && !hub, nb, deg, total, acc, 16, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c, g.mir);
 }
 
 // hub-row-only launches (defined in ss_first_hop.hip / ss_propagate.hip) for kernels that skip hub rows themselves

@@ -175,6 +175,105 @@ class RowShard(object):
             handle.wait()  # the current stream waits for the collective; the host does not block
 
 
+class PeerShard(RowShard):
+    """the row-sharded build WITHOUT an exchange step (DESIGN 6 'rows written straight into the peers' tables'):
+    every rank's kernels store each row they finish into ALL ranks' tables while they run -- the same bytes over xGMI as the
+    per-hop all-gather, spread over the whole kernel, no collective launch -- and a hop boundary needs only a cross-rank barrier.
+
+    The tables are allocated ONCE per shard object and shared through CUDA-IPC handles (hipIpcGetMemHandle under torch's
+    reductions; HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver): a build through this shard returns VIEWS of those buffers, which the
+    shard's next build overwrites (BUDDY builds once; a caller that wants to keep several builds alive makes several shards).
+    At most 8 ranks (SS_MAX_MIRRORS + 1: one node)."""
+    peer_write = True
+
+    def __init__(self, num_nodes, max_hops, num_perm, m, device, group=None):
+        super().__init__(num_nodes, group)
+        from . import _native
+        if self.world - 1 > _native.MAX_MIRRORS:
+            raise ValueError(f'a peer-write build spans at most {_native.MAX_MIRRORS + 1} ranks, got {self.world}')
+        self.device = torch.device(device)
+        self.shape = (max_hops, num_perm, m)
+        rows = self.padded_rows
+        self.mh = [torch.empty((rows, num_perm), dtype=torch.int32, device=device) for _ in range(max_hops)]
+        self.hll = [torch.empty((rows, m), dtype=torch.uint8, device=device) for _ in range(max_hops)]
+        self.cards = torch.empty((rows, max_hops), dtype=torch.float32, device=device)
+        self._token = torch.zeros(1, dtype=torch.float32, device=device)
+        from torch.multiprocessing.reductions import reduce_tensor
+        mine = [reduce_tensor(t) for t in self.mh + self.hll + [self.cards]]
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=group)
+        self._peer_tensors = {}  # keeps the mappings of the peers' memory alive
+        failure = None
+        try:
+            for r in range(self.world):
+                if r == self.rank:
+                    continue
+                opened = [rebuild(*args) for rebuild, args in everyone[r]]
+                for t in opened:
+                    if t.device != self.device:  # another GPU of the node: this GPU must be allowed to address its memory
+                        _enable_peer_access(self.device, t.device)
+                self._peer_tensors[r] = opened
+        except Exception as exc:  # (mapping a peer's memory can fail on ONE rank only: agree before anybody waits for anybody)
+            failure = exc
+        ok = torch.tensor([0.0 if failure else 1.0], device=device if self.native else 'cpu')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if float(ok.item()) < 1.0:
+            raise RuntimeError(f'peer-write build: a rank could not map its peers\' tables (this rank: {failure!r})')
+        self._order = [r for r in range(self.world) if r != self.rank]
+        self.hop_barrier()  # nobody starts storing into a table before everybody has mapped it
+
+    def tables(self, max_hops, num_perm, m, device):
+        if (max_hops, num_perm, m) != self.shape or torch.device(device) != self.device:
+            raise ValueError(f'this shard was made for {self.shape} on {self.device}')
+        return self.mh, self.hll, self.cards
+
+    def mirrors(self, kind, k):
+        """device addresses, inside the OTHER ranks' memory, of the table this rank's launch for (`kind`, hop index k) also writes"""
+        h = self.shape[0]
+        out = []
+        for r in self._order:
+            t = self._peer_tensors[r]
+            if kind == 'mh':
+                out.append(t[k].data_ptr())
+            elif kind == 'hll':
+                out.append(t[h + k].data_ptr())
+            else:
+                out.append(t[2 * h].data_ptr() + 4 * k)  # column k of the peer's cards [rows, h]
+        return out
+
+    def hop_barrier(self):
+        """every rank's launches issued so far are complete (their stores into this rank's tables included) before this rank's
+        NEXT launch starts: RCCL -- a one-element all-reduce on its own stream, the compute stream waits for it, the host does not
+        block; other backends (gloo in the one-GPU tests) -- device synchronisation + a host barrier"""
+        if self.native:
+            dist.all_reduce(self._token, group=self.group, async_op=True).wait()
+        else:
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)
+
+
+def _enable_peer_access(device, other):
+    """make `other`'s memory addressable from kernels running on `device` (and the reverse): torch enables peer access between two
+    devices the first time it copies between them"""
+    a = torch.zeros(1, device=device)
+    b = a.to(other)
+    a.copy_(b)
+    torch.cuda.synchronize(device)
+
+
+def peer_write_build_hash_tables(eh, num_nodes, edge_index, shard=None, group=None):
+    """`eh.build_hash_tables` with the rows of every hop computed once across the group and written straight into every rank's
+    tables (PeerShard).  Pass the shard of an earlier call to reuse its IPC-shared buffers; returns (table, cards, shard)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        table, cards = eh.build_hash_tables(num_nodes, edge_index)
+        return table, cards, None
+    if shard is None:
+        device = edge_index.device if edge_index.is_cuda else torch.device('cuda', torch.cuda.current_device())
+        shard = PeerShard(num_nodes, eh.max_hops, eh.num_perm, eh.m, device, group)
+    table, cards = eh._build(num_nodes, edge_index, shard)
+    return table, cards, shard
+
+
 def sharded_build_hash_tables(eh, num_nodes, edge_index, group=None):
     """`eh.build_hash_tables(num_nodes, edge_index)` with the rows of every hop computed once across the group instead
     of once per rank; every rank passes the SAME edge_index and returns the SAME full (table, cards) -- bit-identical to

@@ -542,14 +542,23 @@ class CsrGraph(object):
         self.fingerprint = None      # device buffer of ss_csr_build_cached (None: never reused)
         self.use_inferred_self_loops = False
 
-    def struct(self, rows=None):
-        """rows = (begin, end): only those destination rows are computed (multi-GPU destination-range sharding)"""
+    def struct(self, rows=None, mirrors=None):
+        """rows = (begin, end): only those destination rows are computed (multi-GPU destination-range sharding).
+        mirrors = (mh_ptrs, hll_ptrs, cards_ptrs): lists of device addresses (0 / None = absent) of the OTHER ranks' tables that
+        receive every finished row as well (peer-write build, dist.PeerShard)"""
         begin, end = (0, 0) if rows is None else rows
         if rows is not None and end == 0:  # (0, 0) would mean "all rows" to the library: express the empty range at N
             begin = end = self.num_nodes
         hubs = self.has_hub_rows
         mega = hubs and self.mega_rows is not None
-        return _native.CsrGraphStruct(rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(), num_nodes=self.num_nodes,
+        extra = {}
+        if mirrors is not None and len(mirrors[0]) > 0:
+            n_mir = len(mirrors[0])
+            if n_mir > _native.MAX_MIRRORS:
+                raise ValueError(f'a peer-write build reaches at most {_native.MAX_MIRRORS} other ranks, got {n_mir}')
+            arr = lambda ptrs: (c_void_p * 7)(*[int(p or 0) for p in ptrs] + [0] * (7 - n_mir))
+            extra = dict(n_mirrors=n_mir, mirror_mh=arr(mirrors[0]), mirror_hll=arr(mirrors[1]), mirror_cards=arr(mirrors[2]))
+        return _native.CsrGraphStruct(**extra, rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(), num_nodes=self.num_nodes,
                                       n_self_loops=0,
                                       n_self_loops_dev=self.n_self_dev.data_ptr() if self.use_inferred_self_loops else None,
                                       hub_threshold=self.hub_threshold, reserved=0,
@@ -688,7 +697,7 @@ class _CsrCache(object):
 _default_csr_cache = _CsrCache()
 
 
-def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, params=None, mh_out=None, hll_out=None, rows=None):
+def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, params=None, mh_out=None, hll_out=None, rows=None, mirrors=None):
     """one hop; returns (mh_out or None, hll_out or None).  mh_in packed int32 [N,P], hll_in uint8 [N,M];
     rows = (begin, end) restricts the destination rows written (inputs are always the full tables)"""
     N = csr.num_nodes
@@ -699,7 +708,7 @@ def _propagate(csr, mh_in, hll_in, device, cards_out=None, cards_stride=0, param
     P = mh_in.size(1) if mh_in is not None else 0
     M = hll_in.size(1) if hll_in is not None else 0
     prm = byref(params.struct) if params is not None else None
-    graph = csr.struct(rows)
+    graph = csr.struct(rows, mirrors)
     with _Span('propagate' if (mh_in is not None and hll_in is not None) else ('propagate_mh' if hll_in is None else 'propagate_hll'), device):
         _native.check(_native.lib().ss_propagate(byref(graph), _ptr(mh_in), _ptr(mh_out), P, _ptr(hll_in), _ptr(hll_out), M,
                                                  _ptr(cards_out), cards_stride, prm, _stream(device)), 'ss_propagate')
@@ -1065,8 +1074,12 @@ class ElphHashes(object):
         # hop 1 from node ids: MinHash for 64 / 128 / 192 / 256 permutations at any hll_p, HLL at hll_p == 8
         fused_mh = self.fuse_first_hop and self.num_perm % 64 == 0 and self.num_perm <= 256
         fused = fused_mh and self.p == 8
-        mh = [torch.empty((n_alloc, self.num_perm), dtype=torch.int32, device=device) for _ in range(h)]
-        hll = [torch.empty((n_alloc, self.m), dtype=torch.uint8, device=device) for _ in range(h)]
+        peer = shard is not None and getattr(shard, 'peer_write', False)
+        if peer:  # the shard's persistent, IPC-shared tables (every rank's launches store into every rank's copy)
+            mh, hll, cards = shard.tables(h, self.num_perm, self.m, device)
+        else:
+            mh = [torch.empty((n_alloc, self.num_perm), dtype=torch.int32, device=device) for _ in range(h)]
+            hll = [torch.empty((n_alloc, self.m), dtype=torch.uint8, device=device) for _ in range(h)]
         if fused:
             # hop 1 is computed straight from node ids (ss_first_hop); the hop-0 tables (pure functions of the node id,
             # never read by get_subgraph_features) are produced only if a caller actually looks at them
@@ -1110,6 +1123,23 @@ class ElphHashes(object):
                     _propagate(csr, mh_prev, hll_prev, device, cards_out=cards[:, k - 1], cards_stride=h, params=params,
                                mh_out=mh[k - 1], hll_out=hll[k - 1])
                 mh_prev, hll_prev = mh[k - 1], hll[k - 1]
+        elif peer:
+            # peer-write: no exchange step -- the kernels store every finished row into all ranks' tables while they run
+            # (csrc: mirror_* stores); a hop may start once EVERY rank's launches of the previous hop are complete
+            if not (fused_mh and fused):
+                raise NotImplementedError('the peer-write build is built for the default sketch shape (128 permutations, hll_p = 8)')
+            for k in range(1, h + 1):
+                mir_mh, mir_hll = shard.mirrors('mh', k - 1), shard.mirrors('hll', k - 1)
+                none = [0] * len(mir_mh)
+                if k == 1:
+                    self._first_hop(csr, device, mh[0], None, None, params, rows=rows, mirrors=(mir_mh, none, none))
+                    self._first_hop(csr, device, None, hll[0], cards, params, rows=rows, mirrors=(none, mir_hll, shard.mirrors('cards', 0)))
+                else:
+                    _propagate(csr, mh[k - 2], None, device, mh_out=mh[k - 1], rows=rows, mirrors=(mir_mh, none, none))
+                    _propagate(csr, None, hll[k - 2], device, cards_out=cards[:, k - 1], cards_stride=h, params=params, hll_out=hll[k - 1],
+                               rows=rows, mirrors=(none, mir_hll, shard.mirrors('cards', k - 1)))
+                shard.hop_barrier()
+            cards = cards[:num_nodes]
         else:
             pending_mh = pending_hll = None
             for k in range(1, h + 1):
@@ -1139,10 +1169,10 @@ class ElphHashes(object):
                 self._deferred.raise_if_set()
         return table, _stamp_tables(cards, self.tables_id)
 
-    def _first_hop(self, csr, device, mh_out, hll_out, cards, params, rows=None):
+    def _first_hop(self, csr, device, mh_out, hll_out, cards, params, rows=None, mirrors=None):
         """fused hop-0 + hop-1 (ss_first_hop) for either or both sketches"""
         ab = self._perms(device)
-        graph = csr.struct(rows)
+        graph = csr.struct(rows, mirrors)
         with _Span('first_hop_mh' if hll_out is None else ('first_hop_hll' if mh_out is None else 'first_hop'), device):
             _native.check(_native.lib().ss_first_hop(byref(graph), _ptr(ab[0]), _ptr(ab[1]), self.num_perm, _ptr(mh_out), self.p,
                                                      _ptr(hll_out), _ptr(cards) if hll_out is not None else None, self.max_hops,

@@ -181,10 +181,12 @@ def test_abi_constants_match_the_header():
     text = open(os.path.join(REPO, 'include', 'subgraph_sketch.h')).read()
     assert int(re.search(r'#define SS_MEGA_SLICE (\d+)', text).group(1)) == _native.MEGA_SLICE
     assert int(re.search(r'#define SS_MEGA_SLOT_BYTES (\d+)', text).group(1)) == _native.MEGA_SLOT_BYTES
+    assert int(re.search(r'#define SS_CSR_FINGERPRINT_BYTES (\d+)', text).group(1)) == _native.CSR_FINGERPRINT_BYTES
+    assert int(re.search(r'#define SS_MAX_MIRRORS (\d+)', text).group(1)) == _native.MAX_MIRRORS
     api = open(os.path.join(REPO, 'subgraph-sketching_amd', 'csrc', 'ss_api.hip')).read()
     assert int(re.search(r'ss_version\(void\) \{ return (\d+);', api).group(1)) == _native.ABI_VERSION
     fields = re.search(r'typedef struct ss_csr_graph \{(.*?)\} ss_csr_graph;', text, re.S).group(1)
-    names = re.findall(r'(\w+);', re.sub(r'/\*.*?\*/', '', fields, flags=re.S))
+    names = re.findall(r'(\w+)(?:\[\d+\])?;', re.sub(r'/\*.*?\*/', '', fields, flags=re.S))   # (array members: name[7];)
     assert names == [f[0] for f in _native.CsrGraphStruct._fields_]   # the ctypes mirror lists the same fields in the same order
 
 
