@@ -5,9 +5,9 @@
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o $TAG -- python $R/bench.py --no-cpu-baseline --no-kernel-table --sustain-seconds 0 "$@" > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o $TAG -- python $R/bench.py --no-cpu-baseline --no-kernel-table --no-secondary --sustain-seconds 0 "$@" > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
 if [ -z "$NO_PMC" ]; then
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG -o ${TAG}_fetch -- python $R/bench.py --no-cpu-baseline --no-kernel-table --sustain-seconds 0 "$@" --steps 3 --warmup 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG -o ${TAG}_write -- python $R/bench.py --no-cpu-baseline --no-kernel-table --sustain-seconds 0 "$@" --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG -o ${TAG}_fetch -- python $R/bench.py --no-cpu-baseline --no-kernel-table --no-secondary --sustain-seconds 0 "$@" --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG -o ${TAG}_write -- python $R/bench.py --no-cpu-baseline --no-kernel-table --no-secondary --sustain-seconds 0 "$@" --steps 3 --warmup 1 > /dev/null 2>&1
 fi
 ls $R/gpurun_out/prof_$TAG

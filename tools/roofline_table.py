@@ -52,7 +52,7 @@ def main():
         fam = next((f for key, f in FAMILIES if key in name), None)
         raw = next((v for k, v in pmc.items() if k.replace('void ', '') == short), None)
         hbm = (2 * raw.get('FETCH_SIZE_KB_avg', 0) + raw.get('WRITE_SIZE_KB_avg', 0)) * 1024 if raw else None
-        if fam:
+        if fam and model[fam] > 0:
             alg = model[fam]
             res = rf.residency(n, fam) if fam in ('minhash_hop', 'hll_hop') else '-'
             lines.append(f'| `{short}` | {r["Calls"]} | {avg / 1e3:.1f} | {alg / 1e9:.4f} GB | {alg / avg:.0f} | {alg / avg / rf.HBM_PEAK_GBS:.3f} | '

@@ -5,7 +5,8 @@
 #   <prefix>            collab-like uniform (BASELINE configs[1], the driver's shape)
 #   <prefix>_ppa        ppa-like uniform (configs[3]; MinHash table 295 MB: HBM-resident)
 #   <prefix>_citation2  citation2-like uniform, h = 3 (configs[4]; 1.5 GB MinHash table: HBM-resident random gathers)
-#   <prefix>_powerlaw   collab-like, endpoint weights ~ rank^-0.5 (hub rows)
+#   <prefix>_powerlaw   collab-like, endpoint weights ~ rank^-0.5 (hub rows); _powerlaw09: rank^-0.9 (mega rows, dense CSR buckets)
+#   <prefix>_ppa_powerlaw / _citation2_powerlaw   the power-law generator at configs[3] / [4] size (rank^-0.5)
 # then: python tools/summarise_prof.py <tag> for each (run in the build container; copies the summaries into profiles/)
 P=$1
 R=$GRAFT_REPO_ROOT
@@ -13,3 +14,7 @@ bash $R/tools/prof.sh $P
 bash $R/tools/prof.sh ${P}_ppa --config ppa --steps 10 --warmup 2
 bash $R/tools/prof.sh ${P}_citation2 --config citation2 --steps 5 --warmup 2
 bash $R/tools/prof.sh ${P}_powerlaw --graph powerlaw --alpha 0.5
+# the power-law generator at the SAME N, E as every config (hub rows, mega rows, dense CSR buckets at size)
+bash $R/tools/prof.sh ${P}_powerlaw09 --graph powerlaw --alpha 0.9
+bash $R/tools/prof.sh ${P}_ppa_powerlaw --config ppa --graph powerlaw --alpha 0.5 --steps 10 --warmup 2
+bash $R/tools/prof.sh ${P}_citation2_powerlaw --config citation2 --graph powerlaw --alpha 0.5 --steps 5 --warmup 2
