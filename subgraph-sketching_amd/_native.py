@@ -30,7 +30,7 @@ class CsrGraphStruct(ctypes.Structure):
                 ('hub_rows', c_void_p), ('hub_count', c_void_p), ('mega_rows', c_void_p), ('mega_count', c_void_p),
                 ('mega_scratch', c_void_p), ('row_begin', c_int64), ('row_end', c_int64),
                 ('n_mirrors', c_int32), ('reserved2', c_int32), ('mirror_mh', c_void_p * 7), ('mirror_hll', c_void_p * 7),
-                ('mirror_cards', c_void_p * 7)]
+                ('mirror_cards', c_void_p * 7), ('hub_report', c_void_p), ('report_hub_count', c_void_p), ('report_mega_count', c_void_p)]
 
 
 ABI_VERSION = 125  # ss_version() of the library this module's struct mirrors and signatures describe

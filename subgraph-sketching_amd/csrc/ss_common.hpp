@@ -283,6 +283,8 @@ struct GraphArgs {  // device-side view of ss_csr_graph
     const int64_t *row_list = nullptr;
     int64_t n_list = 0;
     Mirrors mir = {};
+    int32_t *hub_report = nullptr;  // ss_csr_graph.hub_report and the two device counters it is formed from
+    const int32_t *report_hub_count = nullptr, *report_mega_count = nullptr;
     __host__ __device__ int64_t rows() const { return row1 - row0; }
     __device__ bool owns(int64_t i) const { return i >= row0 && i < row1; }
 };
@@ -294,6 +296,9 @@ inline GraphArgs to_args(const ss_csr_graph &g)
     GraphArgs a{g.rowptr, g.col, g.num_nodes, g.n_self_loops, g.n_self_loops_dev, g.hub_threshold, g.hub_rows, g.hub_count,
                 mega ? const_cast<int32_t *>(g.mega_rows) : nullptr, mega ? g.mega_count : nullptr,
                 mega ? static_cast<uint8_t *>(g.mega_scratch) : nullptr, all ? 0 : g.row_begin, all ? g.num_nodes : g.row_end};
+    a.hub_report = g.report_hub_count ? g.hub_report : nullptr;
+    a.report_hub_count = g.report_hub_count;
+    a.report_mega_count = g.report_mega_count;
     a.mir.n = g.n_mirrors > 0 && g.n_mirrors <= SS_MAX_MIRRORS ? g.n_mirrors : 0;
     for (int m = 0; m < a.mir.n; ++m) {
         a.mir.mh[m] = g.mirror_mh[m];
@@ -301,6 +306,16 @@ inline GraphArgs to_args(const ss_csr_graph &g)
         a.mir.cards[m] = g.mirror_cards[m];
     }
     return a;
+}
+
+// ss_csr_graph.hub_report: one thread of a first-hop launch, at its very start (the launch then runs for tens of microseconds:
+// a store to pinned host memory issued here is long acknowledged when the kernel ends -- the same store by the LAST workgroup of
+// the CSR build's finish launch added 10 us to that launch)
+__device__ __forceinline__ void report_hub_rows(const GraphArgs &g)
+{
+    if (g.hub_report && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(g.hub_report, *g.report_hub_count + (g.report_mega_count ? g.report_mega_count[0] : 0), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // a finished piece of a row also goes to the peers' tables (same element offset; a launch that does not produce a sketch never

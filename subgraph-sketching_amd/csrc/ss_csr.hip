@@ -1205,7 +1205,9 @@ int helper_budget(Kernel kernel)
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kFinishThreads, 0) != hipSuccess) return 0;
     const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
-    const int64_t h = slots / 2 < kDenseHelpers ? slots / 2 : kDenseHelpers;
+    static const int cap_env = getenv("SS_CSR_HELPERS") ? atoi(getenv("SS_CSR_HELPERS")) : 0;  // tuning hook (never above the safe bound)
+    const int64_t cap = cap_env > 0 && cap_env < kDenseHelpers ? cap_env : kDenseHelpers;
+    const int64_t h = slots / 2 < cap ? slots / 2 : cap;
     return (int)(h > 0 ? h : 0);
 }
 

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void first_hop_rows_kernel(GraphArgs g, const 
                                                              uint32_t *__restrict__ mh_out, int p, bool skip_hubs)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    report_hub_rows(g);
     MinhashRows<PPL, R, MIR> m;
     if (!m.init(g, g.row0 + ((int64_t)blockIdx.x * (blockDim.x / kWave) + wave) * R, pa, pb, p, skip_hubs)) return;
     for (int r = 0; r < m.rows; ++r) m.row(r, mh_out);  // wave-uniform
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
     __shared__ EstimatorLds lds;
     __shared__ __attribute__((aligned(16))) uint32_t rows[256 / kRow][256];  // one u32 per register and 16-lane group
     const bool want_cards = cards_out != nullptr;
+    report_hub_rows(g);
     EstimatorTables est;
     if (want_cards) est = stage_tables(lds, prm);
     const int l = threadIdx.x & (kRow - 1);

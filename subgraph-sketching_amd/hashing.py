@@ -540,6 +540,7 @@ class CsrGraph(object):
         self.pending_lazies = []     # weakrefs to every LazyMinhash whose deferred launch refers to this graph
         self.num_edges = None
         self.fingerprint = None      # device buffer of ss_csr_build_cached (None: never reused)
+        self.hub_report = None       # pinned host int32 the first-hop kernels report this graph's hub + mega row count into
         self.use_inferred_self_loops = False
 
     def struct(self, rows=None, mirrors=None):
@@ -552,12 +553,15 @@ class CsrGraph(object):
         hubs = self.has_hub_rows
         mega = hubs and self.mega_rows is not None
         extra = {}
+        if self.hub_report is not None:  # (the device counters of the CSR build -> a pinned host word, see ElphHashes._hub_hint)
+            extra.update(hub_report=self.hub_report.data_ptr(), report_hub_count=self.hub_count.data_ptr(),
+                         report_mega_count=self.mega_count.data_ptr() if self.mega_count is not None else None)
         if mirrors is not None and len(mirrors[0]) > 0:
             n_mir = len(mirrors[0])
             if n_mir > _native.MAX_MIRRORS:
                 raise ValueError(f'a peer-write build reaches at most {_native.MAX_MIRRORS} other ranks, got {n_mir}')
             arr = lambda ptrs: (c_void_p * 7)(*[int(p or 0) for p in ptrs] + [0] * (7 - n_mir))
-            extra = dict(n_mirrors=n_mir, mirror_mh=arr(mirrors[0]), mirror_hll=arr(mirrors[1]), mirror_cards=arr(mirrors[2]))
+            extra.update(n_mirrors=n_mir, mirror_mh=arr(mirrors[0]), mirror_hll=arr(mirrors[1]), mirror_cards=arr(mirrors[2]))
         return _native.CsrGraphStruct(**extra, rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(), num_nodes=self.num_nodes,
                                       n_self_loops=0,
                                       n_self_loops_dev=self.n_self_dev.data_ptr() if self.use_inferred_self_loops else None,
@@ -923,18 +927,25 @@ class ElphHashes(object):
         # link sets of >= GROUP_LINKS_MIN pairs: 'auto' = grouped by their first node unless the list already has its runs (one
         # host read per such call), True = always grouped, False = walked as listed (no host read)
         self.group_links = 'auto'
+        # skip the hub-pass launches of build_hash_tables for shapes whose earlier builds listed no hub rows (see _hub_hint)
+        self.hub_hints = os.environ.get('SS_HUB_HINTS', '1') != '0'
+        self._hub_words = {}
 
     # no device handles in pickled state (SURVEY.md section 8(b) threading row)
     def __getstate__(self):
         state = dict(self.__dict__)
         state['_dev_params'], state['_dev_perms'] = {}, {}
         state['_csr_cache'], state['_deferred'] = None, None
+        state['_hub_words'] = {}
         state.pop('_tables_id', None)
         state['minhash_prop'], state['hll_prop'] = None, None
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self.__dict__.setdefault('hub_hints', os.environ.get('SS_HUB_HINTS', '1') != '0')
+        self.__dict__.setdefault('group_links', 'auto')
+        self._hub_words = {}
         self._deferred = _DeferredErrors()
         self._csr_cache = _CsrCache(self._bounds)
         self.minhash_prop = MinhashPropagation(self._csr_cache, self._report_after_host_copy, self.__dict__.get('_defer_first_hop'),
@@ -1042,6 +1053,21 @@ class ElphHashes(object):
             return False, self._deferred.flag(device, what)
         return bool(self.strict_bounds), None
 
+    def _hub_hint(self, device, num_nodes, edge_index):
+        """-> (pinned host word a build of this shape reports its hub + mega row count into, whether an EARLIER build of
+        the shape reported none).  The word is read without synchronising -- it holds whatever the most recent COMPLETED build of
+        the shape left (-1: none yet) -- and is only a hint: with it, an unskewed graph is built without the two hub-pass launches
+        per hop that find nothing to do (9 us of a 0.455 ms step at ogbl-collab size); if the hint is stale (another graph of the
+        same shape that does have hub rows) those rows are walked by single wavefronts once -- slow, never wrong -- and the next
+        build of the shape has its hub passes back.  `eh.hub_hints = False` keeps the passes unconditionally."""
+        key = (str(device), int(num_nodes), tuple(edge_index.shape), HUB_THRESHOLD)
+        word = self._hub_words.get(key)
+        if word is None:
+            if len(self._hub_words) >= 16:
+                self._hub_words.pop(next(iter(self._hub_words)))
+            word = self._hub_words[key] = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+        return word, int(word[0]) == 0
+
     def check_errors(self):
         """strict_bounds = 'deferred': wait for the launches issued so far and raise IndexError if any of them met a node id
         outside its num_nodes (call once after preprocessing / at the end of an epoch; every call into the engine also
@@ -1064,7 +1090,11 @@ class ElphHashes(object):
         # add_self_loops without num_nodes (reference :148): loops for i < max(edge_index) + 1 only; the count is
         # produced on the device by ss_csr_build and read by the propagation kernel -- no host round trip
         check, err_flag = self._bounds(device, f'build_hash_tables(num_nodes={num_nodes})')
+        report, no_hubs = (None, False) if (check or not self.hub_hints) else self._hub_hint(device, num_nodes, edge_index)
         csr = build_csr(edge_index, num_nodes, device, check=check, err_flag=err_flag)
+        csr.hub_report = report  # (the first-hop kernels of this build leave its hub + mega row count there)
+        if no_hubs:  # an earlier build of this shape listed no hub / mega rows: no hub passes (the row kernels walk every row)
+            csr.has_hub_rows = False
         csr.use_inferred_self_loops = True
         rows = None if shard is None else shard.rows
         n_alloc = num_nodes if shard is None else shard.padded_rows
