@@ -29,6 +29,9 @@
 namespace ss {
 
 constexpr int kThreads = 256;
+#ifndef SS_COUNT_DEPTH
+#define SS_COUNT_DEPTH 4
+#endif
 constexpr int kTile = 4096;            // edges sorted in LDS at a time by the scatter step
 constexpr int kMaxKeys = 256;          // partition fan-out per pass
 constexpr int kMaxBlocks1 = 2048;      // pass-1 slices
@@ -67,6 +70,16 @@ struct CsrPlan {
     int tiles;            // 4096-edge tiles (gather plan)
 };
 
+// average edges of a fine bucket the multi-pass plans aim for.  The finish step stages kFinishCap = 16 384 edges in LDS; a bucket
+// above that takes node sub-ranges, above kDenseMin it is split by edges over several workgroups -- which is why the target can sit
+// at 3/4 of the cap instead of the former 1/2: half as many finish workgroups, each with the same fixed latencies (ppa-size graph:
+// finish 247 -> 186 us, build 888 -> 813 us; citation2-size: 337 -> 247 us, 1 228 -> 1 117 us).  SS_CSR_BUCKET_EDGES: tuning hook
+inline int64_t bucket_edges_target()
+{
+    static const int64_t env = getenv("SS_CSR_BUCKET_EDGES") ? atoll(getenv("SS_CSR_BUCKET_EDGES")) : 0;
+    return env > 0 ? env : kFinishCap * 3 / 4;
+}
+
 inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
 {
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31)) return false;
@@ -76,7 +89,7 @@ inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
     // average, between 64 and 1024 nodes
     int shift = 10;
     if (((n + 1023) >> 10) > kMaxKeys)
-        while (shift > 6 && (E / n) * ((int64_t)1 << shift) > kFinishCap / 2) --shift;
+        while (shift > 6 && (E / n) * ((int64_t)1 << shift) > bucket_edges_target()) --shift;
     if (const char *forced = getenv("SS_CSR_NODE_SHIFT")) {  // test hook: reach the multi-pass plans with small graphs
         const int f = atoi(forced);
         if (f >= 4 && f <= 10) shift = f;
@@ -114,7 +127,11 @@ inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
     if (b1 > kMaxBlocks1) b1 = kMaxBlocks1;
     p.blocks1 = (int)b1;
     p.slice1 = (E + b1 - 1) / b1;
-    int parts = 2048 / (p.keys1 > 0 ? p.keys1 : 1);
+    // workgroups of a second / third partition pass: a FIXED number per bucket of the pass before, so a skewed graph's largest
+    // bucket decides how long the pass takes -- 8 192 in all (2 048: ppa-size graph with rank^-0.5 endpoints 1 191 us per build,
+    // 8 192: 883 us; the uniform graph 889 us either way).  SS_CSR_PARTS: tuning hook
+    static const int parts_budget = getenv("SS_CSR_PARTS") ? atoi(getenv("SS_CSR_PARTS")) : 8192;
+    int parts = (parts_budget > 0 ? parts_budget : 8192) / (p.keys1 > 0 ? p.keys1 : 1);
     if (parts < 1) parts = 1;
     if (parts > 64) parts = 64;
     p.parts2 = parts;
@@ -250,6 +267,7 @@ struct PassArgs {
     int64_t E, N, slice;                 // pass 1
     int shift, sub_shift, keys, parts;   // key = dst >> shift (pass 1) | (dst >> sub_shift) - (bucket << (shift - sub_shift)) (pass 2)
     const int32_t *skip;                 // nullable: *skip != 0 -> the outputs already hold this CSR (ss_csr_build_cached), every kernel exits
+    int32_t *bad_record;                 // nullable: set beside *err when ids out of range are met (FingerprintWords.bad)
 };
 
 // first statement of every kernel of a build (workgroup-uniform: one word)
@@ -307,10 +325,11 @@ __global__ __launch_bounds__(kThreads) void count_keys_kernel(PassArgs a, uint32
     int group, part, parts;
     block_range<PASS2>(a, lo, hi, group, part, parts);
     bool bad = false;
-    for (int64_t e0 = lo; e0 < hi; e0 += 4 * kThreads) {
-        int64_t d[4];
+    constexpr int kDepth = SS_COUNT_DEPTH;  // loads in flight per thread
+    for (int64_t e0 = lo; e0 < hi; e0 += kDepth * kThreads) {
+        int64_t d[kDepth];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kDepth; ++k) {
             const int64_t e = e0 + threadIdx.x + (int64_t)k * kThreads;
             d[k] = -1;
             if (e < hi) {
@@ -327,10 +346,11 @@ __global__ __launch_bounds__(kThreads) void count_keys_kernel(PassArgs a, uint32
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < kDepth; ++k)
             if (d[k] >= 0) atomicAdd(&hist[key_of<PASS2>(a, d[k], group)], 1u);
     }
     if (bad && err) *err = 1;
+    if (bad && a.bad_record) *a.bad_record = 1;
     __syncthreads();
     if ((int)threadIdx.x < a.keys) counts[((int64_t)group * a.keys + threadIdx.x) * parts + part] = hist[threadIdx.x];
 }
@@ -495,6 +515,7 @@ __global__ __launch_bounds__(kScatterThreads) void scatter_tiles_kernel(PassArgs
         }
         if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(&block_max, m);
         if (bad && err) *err = 1;
+        if (bad && a.bad_record) *a.bad_record = 1;
         __syncthreads();
         if (threadIdx.x == 0 && block_max) atomicMax(n_self, block_max);
     }
@@ -733,7 +754,7 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
                                                                  uint32_t *__restrict__ tile_off, unsigned long long *__restrict__ tile_max,
                                                                  int32_t *__restrict__ err, int32_t *__restrict__ hub_count,
                                                                  int32_t *__restrict__ mega_count, int32_t *__restrict__ dense_count,
-                                                                 const int32_t *__restrict__ skip)
+                                                                 const int32_t *__restrict__ skip, int32_t *__restrict__ bad_record)
 {
     __shared__ int2 sorted[kTile];
     __shared__ uint32_t tile_hist[kMaxKeys], tile_offs[kMaxKeys], wave_tot[kSortThreads / kWave];
@@ -795,6 +816,7 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
     }
     if (lane == 0 && m) atomicMax(&block_max, m);
     if (bad && err) *err = 1;
+    if (bad && bad_record) *bad_record = 1;
     __syncthreads();
     if (threadIdx.x == 0) tile_max[blockIdx.x] = block_max;
 }
@@ -1132,6 +1154,7 @@ constexpr int kFpBlocks = 512;
 struct FingerprintWords {  // layout of the caller's device buffer (SS_CSR_FINGERPRINT_BYTES)
     unsigned long long stored[2];
     int32_t valid, skip;
+    int32_t bad, pad;  // the build that produced the cached CSR met ids out of range (re-reported when a later call is skipped)
     unsigned long long partial[kFpBlocks][2];
 };
 static_assert(sizeof(FingerprintWords) <= SS_CSR_FINGERPRINT_BYTES, "SS_CSR_FINGERPRINT_BYTES");
@@ -1167,7 +1190,8 @@ __global__ __launch_bounds__(256) void fingerprint_kernel(const int64_t *__restr
 
 // one workgroup: sums of the partials (+ the shape, so that another N / E / hub threshold never matches) against the stored
 // ones -> skip word; the new sums are stored: after this build the outputs hold the CSR of THIS edge list either way
-__global__ __launch_bounds__(kFpBlocks) void fingerprint_decide_kernel(FingerprintWords *__restrict__ fp, int64_t E, int64_t N, int hub_threshold)
+__global__ __launch_bounds__(kFpBlocks) void fingerprint_decide_kernel(FingerprintWords *__restrict__ fp, int64_t E, int64_t N, int hub_threshold,
+                                                                       int32_t *__restrict__ err)
 {
     __shared__ unsigned long long red[2][kFpBlocks / kWave];
     unsigned long long a = fp->partial[threadIdx.x][0], b = fp->partial[threadIdx.x][1];
@@ -1187,7 +1211,12 @@ __global__ __launch_bounds__(kFpBlocks) void fingerprint_decide_kernel(Fingerpri
         }
         a ^= hash_u64((uint64_t)E * 0x9E3779B97F4A7C15ULL + (uint64_t)N);
         b ^= hash_u64((uint64_t)N * 0xC2B2AE3D27D4EB4FULL + (uint64_t)(uint32_t)hub_threshold + ((uint64_t)E << 20));
-        fp->skip = (fp->valid == 1 && fp->stored[0] == a && fp->stored[1] == b) ? 1 : 0;
+        const int skip = (fp->valid == 1 && fp->stored[0] == a && fp->stored[1] == b) ? 1 : 0;
+        fp->skip = skip;
+        // the same edge list again: what its build reported is reported again (the reference raises on every call with bad ids);
+        // a new edge list: its build records afresh
+        if (skip && fp->bad && err) *err = 1;
+        if (!skip) fp->bad = 0;
         fp->stored[0] = a;
         fp->stored[1] = b;
         fp->valid = 1;
@@ -1238,7 +1267,8 @@ extern "C" size_t ss_csr_workspace_bytes(int64_t N, int64_t E)
 static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                           int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
                           int32_t *mega_rows, int32_t *mega_count,
-                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *skip = nullptr);
+                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *skip = nullptr,
+                          int32_t *bad_record = nullptr);
 
 extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                             int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
@@ -1253,8 +1283,8 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
 // ss_csr_build that first compares a content fingerprint of (src, dst) with the one the previous call left in `fingerprint`
 // (device buffer of SS_CSR_FINGERPRINT_BYTES, zeroed by the caller before its first use, tied to THESE output buffers): equal ->
 // the outputs already hold this CSR and every kernel of the build exits at once; different (or first use) -> an ordinary build,
-// after which `fingerprint` describes the new contents.  No host synchronisation either way.  err_flag is only written by a
-// build that runs.  (reference models/elph.py:186 + runners/train.py:188-198: the same edges in a fresh tensor every step)
+// after which `fingerprint` describes the new contents.  No host synchronisation either way.  A skipped call re-reports (err_flag)
+// the out-of-range ids the build of the cached CSR met.  (reference models/elph.py:186 + runners/train.py:188-198: the same edges in a fresh tensor every step)
 extern "C" int ss_csr_build_cached(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                                    int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
                                    int32_t *mega_rows, int32_t *mega_count, int32_t *err_flag, void *workspace, size_t workspace_bytes,
@@ -1266,10 +1296,10 @@ extern "C" int ss_csr_build_cached(const int64_t *src, const int64_t *dst, int64
     FingerprintWords *fp = reinterpret_cast<FingerprintWords *>(fingerprint);
     hipLaunchKernelGGL(fingerprint_kernel, dim3(kFpBlocks), dim3(256), 0, stream, src, dst, E, fp);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fingerprint_decide_kernel, dim3(1), dim3(kFpBlocks), 0, stream, fp, E, N, (int)hub_threshold);
+    hipLaunchKernelGGL(fingerprint_decide_kernel, dim3(1), dim3(kFpBlocks), 0, stream, fp, E, N, (int)hub_threshold, err_flag);
     SS_LAUNCH_CHECK();
     return csr_build_impl(src, dst, E, N, rowptr, col, n_self_loops_out, hub_threshold, hub_rows, hub_count, mega_rows, mega_count, err_flag,
-                          workspace, workspace_bytes, stream_, &fp->skip);
+                          workspace, workspace_bytes, stream_, &fp->skip, &fp->bad);
 }
 
 // The pairs of a query grouped by their first node (reference hashing.py:270-274 reads cards[u] / the rows of u once per PAIR;
@@ -1289,7 +1319,7 @@ extern "C" int ss_group_links_by_source(const int64_t *links, int64_t B, int64_t
 static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                           int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
                           int32_t *mega_rows, int32_t *mega_count,
-                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *skip)
+                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *skip, int32_t *bad_record)
 {
     using namespace ss;
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || !rowptr) return SS_ERR_INVALID_ARG;
@@ -1320,7 +1350,7 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
 
     if (p.gather) {  // <= 256 fine buckets and <= kMaxTiles tiles: two launches, no counting pass, no scan kernels
         hipLaunchKernelGGL(tile_sort_kernel, dim3(p.tiles), dim3(kSortThreads), 0, stream, src, dst, E, N, p.shift1, p.keys1, p.tiles, w.staged_a,
-                           w.tile_off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip);
+                           w.tile_off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip, bad_record);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(finish_gather_kernel, dim3((unsigned)(p.fine_buckets + helpers)), dim3(kFinishThreads), 0, stream, w.staged_a,
                            w.tile_off, w.tile_max, p.tiles, p.keys1, p.node_shift, N, col, n_self, rows_out, dense);
@@ -1336,7 +1366,7 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
     }
     // ---- pass 1 ----
     PassArgs a1 = {};
-    a1.src = src; a1.dst = dst; a1.E = E; a1.N = N; a1.slice = p.slice1; a1.shift = p.shift1; a1.keys = p.keys1; a1.skip = skip;
+    a1.src = src; a1.dst = dst; a1.E = E; a1.N = N; a1.slice = p.slice1; a1.shift = p.shift1; a1.keys = p.keys1; a1.skip = skip; a1.bad_record = bad_record;
     hipLaunchKernelGGL(count_keys_kernel<false>, dim3(p.blocks1), dim3(kThreads), 0, stream, a1, w.counts1, err_flag, n_self, hub_count,
                        mega_count, w.dense_count);
     SS_LAUNCH_CHECK();

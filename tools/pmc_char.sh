@@ -5,7 +5,7 @@ TAG=$1; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for M in VALUBusy VALUUtilization MemUnitBusy MemUnitStalled LdsBankConflict L2CacheHit MeanOccupancyPerCU SALUBusy; do
-  rocprofv3 --pmc $M --kernel-trace --output-format csv -d $R/gpurun_out/pmcc_$TAG -o ${TAG}_$M -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > /dev/null 2>&1
+  rocprofv3 --pmc $M --kernel-trace --output-format csv -d $R/gpurun_out/pmcc_$TAG -o ${TAG}_$M -- python $R/bench.py --no-cpu-baseline --no-secondary --no-kernel-table --sustain-seconds 0 --steps 3 --warmup 1 "$@" > /dev/null 2>&1
 done
 python - <<PY
 import csv, glob, os, collections
