@@ -122,3 +122,40 @@ def test_mega_row_handoff_under_memory_pressure(regenerated_tables):
     assert not csr.mega_rows[:N_MEGA, 3].any()  # every ticket counter is back to zero
     # the whole table of the last repetition, not only the mega rows
     assert torch.equal(out_mh, mh2) and torch.equal(out_hl, hl2)
+
+
+def test_dense_bucket_helpers_under_memory_pressure():
+    """the CSR build's helper workgroups (ss_csr.hip dense_helper): bucket workgroups REGISTER dense buckets and publish their
+    descriptors + zeroed counters (release -> arrival counter), helpers wait for every bucket, count their shares into global per-node
+    counters, meet at a counter barrier and place the sources.  300 builds of a graph whose first buckets hold most of the edges,
+    while a second stream saturates the memory system; every build's CSR is compared on the device with the first one's row
+    multisets (which is checked against a host counting sort); both plans: the two-launch gather plan and the partition plan."""
+    import os
+    import subgraph_sketching_amd as ssa
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(3)
+    for n, e_und, force_partition in ((120_000, 900_000, False), (400_000, 3_000_000, True)):
+        w = np.arange(1, n + 1, dtype=np.float64) ** -0.9
+        cdf = np.cumsum(w / w.sum())
+        e = np.stack([np.minimum(np.searchsorted(cdf, rng.random_sample(e_und)), n - 1), rng.randint(0, n, size=e_und)]).astype(np.int64)
+        ei_np = np.concatenate([e, e[::-1]], axis=1)
+        ei = torch.from_numpy(ei_np).to(dev)
+        E = ei.size(1)
+        deg = torch.bincount(ei[1], minlength=n)
+        want_rowptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(deg, 0)])
+        want_keys = torch.sort(ei[1] * n + ei[0])[0]                      # (row, source) pairs, sorted: the row multisets
+        rows_of = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+        hog = _Hog(dev)
+        bad = torch.zeros(2, dtype=torch.int64, device=dev)
+        n_dense = None
+        for rep in range(300 if not force_partition else 60):
+            hog.kick()
+            csr = ssa.build_csr(ei, n, dev, check=False)
+            bad[0] += (csr.rowptr != want_rowptr).sum()
+            got = torch.sort(rows_of * n + csr.col[:E].to(torch.int64))[0]
+            bad[1] += (got != want_keys).sum()
+        torch.cuda.synchronize(dev)
+        assert bad.cpu().tolist() == [0, 0], f'n={n}: rowptr / col mismatches over the repetitions: {bad.cpu().tolist()}'
+        assert int(deg.max()) > 4 * ssa._native.MEGA_SLICE
+        # the graph really takes the dense path: some 1024-node (or smaller) bucket holds far more than 32 768 edges
+        assert int(deg[:64].sum()) > 32768
