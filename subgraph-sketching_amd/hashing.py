@@ -679,11 +679,13 @@ class _CsrCache(object):
     self-looped edge_index object; this builds its CSR once per forward.  A dead weak reference or a
     bumped `_version` (in-place edit) invalidates the entry, so recycled allocations are never trusted."""
 
-    def __init__(self, check=lambda device, what: (True, None)):
+    def __init__(self, check=lambda device, what: (True, None), hub_hint=None):
         self._ref, self._version, self._key, self._csr = None, None, None, None
         # (device, what) -> (check, err_flag) of build_csr: whether a build may synchronise to raise IndexError, or where it
         # reports instead (ElphHashes._bounds of the owner)
         self._check = check
+        # (device, num_nodes, edge_index) -> (pinned report word, whether an earlier build of the shape listed no hub rows) or None
+        self._hub_hint = hub_hint
 
     def get(self, edge_index, num_nodes, device):
         key = (num_nodes, tuple(edge_index.shape), str(device))
@@ -694,6 +696,10 @@ class _CsrCache(object):
         # differ, decided on the device (REUSE_CSR_BY_CONTENT; strict builds read their flags back and always rebuild)
         reuse = self._csr if (REUSE_CSR_BY_CONTENT and self._key == key) else None
         csr = build_csr(edge_index, num_nodes, device, check=check, err_flag=err_flag, reuse=reuse, fingerprint=REUSE_CSR_BY_CONTENT)
+        if self._hub_hint is not None and not check:  # (ElphHashes._hub_hint: no hub-pass launches for shapes that listed no hub rows)
+            hint = self._hub_hint(device, num_nodes, edge_index)
+            if hint is not None:
+                csr.hub_report, csr.has_hub_rows = hint[0], not hint[1]
         self._ref, self._version, self._key, self._csr = weakref.ref(edge_index), edge_index._version, key, csr
         return csr
 
@@ -897,7 +903,7 @@ class ElphHashes(object):
         self._minhash_range = (1 << 32)
         self.minhash_seed = 1
         self.num_perm = args.minhash_num_perm
-        self._csr_cache = _CsrCache(self._bounds)
+        self._csr_cache = _CsrCache(self._bounds, self._prop_hub_hint)
         self.minhash_prop = MinhashPropagation(self._csr_cache, self._report_after_host_copy, defer_first_hop, defer_table_hop)
         # hll params (reference hashing.py:65-81)
         self.p = args.hll_p
@@ -947,7 +953,7 @@ class ElphHashes(object):
         self.__dict__.setdefault('group_links', 'auto')
         self._hub_words = {}
         self._deferred = _DeferredErrors()
-        self._csr_cache = _CsrCache(self._bounds)
+        self._csr_cache = _CsrCache(self._bounds, self._prop_hub_hint)
         self.minhash_prop = MinhashPropagation(self._csr_cache, self._report_after_host_copy, self.__dict__.get('_defer_first_hop'),
                                                self.__dict__.get('_defer_table_hop'))
         self.hll_prop = HllPropagation(self._csr_cache, self._params, self.m, self._report_after_host_copy)
@@ -1052,6 +1058,10 @@ class ElphHashes(object):
             self._deferred.raise_if_set()
             return False, self._deferred.flag(device, what)
         return bool(self.strict_bounds), None
+
+    def _prop_hub_hint(self, device, num_nodes, edge_index):
+        """the same hint for the CSR of hll_prop / minhash_prop (the ELPH call sequence)"""
+        return self._hub_hint(device, num_nodes, edge_index) if getattr(self, 'hub_hints', False) else None
 
     def _hub_hint(self, device, num_nodes, edge_index):
         """-> (pinned host word a build of this shape reports its hub + mega row count into, whether an EARLIER build of
