@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
         // (the id of the lane's NEXT neighbour is requested before the current one is hashed -- unconditionally, from an address
         // that always exists: rows of more than 16 neighbours otherwise pay one exposed round trip per 16 neighbours)
         int cur = nid0[r];
+        int fresh = 0;  // registers this lane was the FIRST to set (the LDS atomic returns what was there: 0 exactly once per register)
         for (int t = l; t < total; t += kRow) {
             const int nxt = *(t + kRow < deg ? nb + t + kRow : always_valid);
             const int64_t nid = t < deg ? (int64_t)cur : i;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
             const uint64_t hv = hash_u64((uint64_t)(nid + 1));
             const uint64_t bits = hv >> p;
             const int bl = bits ? 64 - __builtin_clzll(bits) : 0;
-            atomicMax(&row[(uint32_t)hv & 255u], (uint32_t)((64 - p) - bl + 1));
+            fresh += atomicMax(&row[(uint32_t)hv & 255u], (uint32_t)((64 - p) - bl + 1)) == 0u ? 1 : 0;  // (ranks are >= 1)
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // lane l owns registers 16l .. 16l+15
@@ -206,12 +207,20 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
         int nonzero = 0;
         float hsum = 0.0f;
         if (want_cards) {
-            hll_dword_stats(packed.x, nonzero, hsum);
-            hll_dword_stats(packed.y, nonzero, hsum);
-            hll_dword_stats(packed.z, nonzero, hsum);
-            hll_dword_stats(packed.w, nonzero, hsum);
-            nonzero = row16_sum_i(nonzero);
-            hsum = row16_sum_f(hsum);
+            // A hop-1 row has at most deg + 1 non-zero registers, so nearly every row -- every one below 147 neighbours at p = 8 --
+            // is estimated by linear counting, which needs the number of zero registers and nothing else (hashing.py:221-226):
+            // that number comes out of the atomics above.  Only a wavefront holding a row that leaves the linear-counting range
+            // digests the packed registers for the harmonic sum (12 instructions per dword, a third of this kernel's VALU work).
+            nonzero = row16_sum_i(fresh);
+            const int zeros = 256 - nonzero;
+            if (__any(!(zeros > 0 && zeros >= est.lc_min_zeros))) {  // wave-uniform
+                int nz2 = 0;
+                hll_dword_stats(packed.x, nz2, hsum);
+                hll_dword_stats(packed.y, nz2, hsum);
+                hll_dword_stats(packed.z, nz2, hsum);
+                hll_dword_stats(packed.w, nz2, hsum);
+                hsum = row16_sum_f(hsum);
+            }
         }
         if (ok && !hub) {
             *reinterpret_cast<u32x4 *>(hll_out + i * 256 + 16 * l) = packed;
