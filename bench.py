@@ -214,7 +214,7 @@ def secondary_case(ssa, dev, name, config, graph='uniform', alpha=0.5, api='buil
                if frac and frac > 1.0 else {})}
 
 
-def strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank, reps=3):
+def strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank, reps=3, with_peer=False):
     """after the timed region, N > 1: t(1 GPU) and t(N GPUs) of the same two jobs, max over ranks; see the call site"""
     nf = h * (h + 2)
     L = min(cfg['buddy_links'], 64 * batch)
@@ -244,11 +244,17 @@ def strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank
     sharded = lambda: ssa.dist.sharded_build_hash_tables(eh, n, ei)
     builds = [('replicated_build', replicated), ('sharded_build', sharded)]
     res = {'exchange': exchange, 'exchange_probe_seconds': ssa.dist.exchange_probe_times(dev), 'world': world}
-    try:  # peer-write: needs the ranks to map each other's tables (CUDA-IPC); its constructor fails on every rank or on none
-        shard = ssa.dist.PeerShard(n, eh.max_hops, eh.num_perm, eh.m, dev)
-        builds.append(('peer_write_build', lambda: ssa.dist.peer_write_build_hash_tables(eh, n, ei, shard=shard)[:2]))
-    except Exception as exc:
-        res['peer_write_build_unavailable'] = f'{type(exc).__name__}: {exc}'
+    if with_peer:
+        # peer-write: the ranks map each other's tables (CUDA-IPC) and store into them from inside the kernels.  Opt-in
+        # (--strong-peer): validated with processes sharing ONE GPU only -- a node where a rank cannot address a peer's memory
+        # would fault inside a kernel, and the default line must not depend on that.  The constructor fails on every rank or on none.
+        try:
+            shard = ssa.dist.PeerShard(n, eh.max_hops, eh.num_perm, eh.m, dev)
+            builds.append(('peer_write_build', lambda: ssa.dist.peer_write_build_hash_tables(eh, n, ei, shard=shard)[:2]))
+        except Exception as exc:
+            res['peer_write_build_unavailable'] = f'{type(exc).__name__}: {exc}'
+    else:
+        res['peer_write_build'] = 'not measured (opt-in: --strong-peer, or --build peer --scaling strong)'
     for name, links in (('buddy_precompute', links_all), ('build_plus_one_global_batch', links_all[:batch])):
         t1 = timed(lambda: job(links, replicated, False))
         row = {'pairs': links.size(0), 'ms_1gpu_same_work': t1}
@@ -307,6 +313,7 @@ def main():
                          'every rank\'s kernels store their rows straight into all ranks\' (IPC-mapped) tables: no exchange step')
     ap.add_argument('--sustain-seconds', type=float, default=8.0,
                     help='length of the sustained run after the timed region (0 = skip); long enough for a 5 s utilisation sampler')
+    ap.add_argument('--strong-peer', action='store_true', help='N > 1: add the peer-write build to the strong-scaling figures (maps peers\' memory through CUDA-IPC)')
     ap.add_argument('--no-strong', action='store_true', help='N > 1: skip the strong-scaling figures measured after the timed region')
     ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` shapes measured after the timed region')
     ap.add_argument('--no-kernel-table', action='store_true', help='skip the per-kernel HIP-event table (extra steps after the timed region)')
@@ -574,7 +581,7 @@ def main():
     # row-sharded (exchange form chosen by dist.choose_exchange's micro-probe).  speedup_vs_n1_same_work = t(1 GPU) / t(N GPUs).
     if launched and world > 1 and a.api == 'build_query' and not a.no_strong:
         try:
-            out['strong'] = strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank)
+            out['strong'] = strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank, with_peer=a.strong_peer)
         except Exception as exc:  # (deterministic failures are the same on every rank; the headline line must survive)
             out['strong'] = {'error': f'{type(exc).__name__}: {exc}'}
     default_line = a.config == 'collab' and a.graph == 'uniform' and a.api == 'build_query' and batch == cfg['batch']
