@@ -1009,9 +1009,9 @@ __global__ __launch_bounds__(kFinishThreads) void dense_place_kernel(const int2 
 // Instead the finish launch carries `helpers` extra workgroups (blockIdx >= the number of fine buckets): a helper waits until every
 // bucket workgroup has decided (count[2], bumped right after a bucket's size is known), leaves if nothing was registered, and
 // otherwise runs the count step over its shares, meets the other helpers at a counter barrier (count[3]) and runs the place step.
-// No deadlock whatever the dispatch order: bucket workgroups never wait for anybody, and the host sizes `helpers` to at most HALF
+// No deadlock whatever the dispatch order: bucket workgroups never wait for anybody, and the host sizes `helpers` to at most a QUARTER (half would do for one process; two may share a GPU) of
 // the workgroups of this kernel the device can hold, so waiting helpers can never occupy every slot the bucket workgroups (or the
-// helpers still to be dispatched) need.  Hand-offs follow cdna_hip_programming.md Guideline 16: producer stores -> barrier ->
+// helpers still to be dispatched) need -- the host actually stays at a quarter, for processes that share a GPU.  Hand-offs follow cdna_hip_programming.md Guideline 16: producer stores -> barrier ->
 // lane-0 agent release fence -> s_waitcnt vmcnt(0) -> relaxed agent atomic; consumer relaxed poll -> agent acquire fence -> barrier.
 // wave 0 polls the sum of `words` counters `stride` ints apart until it reaches `target`; everybody leaves behind an acquire
 __device__ __forceinline__ void wait_for_count(int32_t *first, int words, int stride, int target)
@@ -1223,9 +1223,9 @@ __global__ __launch_bounds__(kFpBlocks) void fingerprint_decide_kernel(Fingerpri
     }
 }
 
-// helper workgroups a finish launch may carry: at most HALF the workgroups of that kernel the device can hold at once (see
-// dense_helper for why that bound excludes a deadlock), at most kDenseHelpers; 0 = use the stand-alone dense launches
-constexpr int kDenseHelpers = 256;
+// helper workgroups a finish launch may carry: at most a QUARTER of the workgroups of that kernel the device can hold at once
+// (see dense_helper for why such a bound excludes a deadlock), at most kDenseHelpers; 0 = use the stand-alone dense launches
+constexpr int kDenseHelpers = 128;  // (32 .. 256 helpers finish a rank^-0.9 collab-size graph in the same time: shares outnumber none of them)
 template <typename Kernel>
 int helper_budget(Kernel kernel)
 {
@@ -1236,7 +1236,7 @@ int helper_budget(Kernel kernel)
     const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
     static const int cap_env = getenv("SS_CSR_HELPERS") ? atoi(getenv("SS_CSR_HELPERS")) : 0;  // tuning hook (never above the safe bound)
     const int64_t cap = cap_env > 0 && cap_env < kDenseHelpers ? cap_env : kDenseHelpers;
-    const int64_t h = slots / 2 < cap ? slots / 2 : cap;
+    const int64_t h = slots / 4 < cap ? slots / 4 : cap;  // a QUARTER: two processes sharing one GPU still leave half of it to bucket workgroups
     return (int)(h > 0 ? h : 0);
 }
 
