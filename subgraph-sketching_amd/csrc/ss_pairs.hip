@@ -27,6 +27,10 @@ struct PairTables {
     const uint8_t *hll[SS_MAX_HOPS];
 };
 
+// (measured and rejected in round 3: counting equal dwords as 4 - sum(min(a ^ b, 1)) instead of v_cmp_eq_u32 + v_addc_co_u32 -- hipcc
+// puts an `s_nop 1` behind each of the 72 compares of a pair at h = 3, gfx950 wanting two wait states between a VALU write of VCC
+// and its VALU read -- removes 59 of 102 s_nops but adds 47 VALU instructions: level on cache-resident tables, 3.5 % SLOWER on
+// citation2-size tables (3 713 against 3 580 us for 4 M pairs): other wavefronts fill the wait states, nobody fills extra instructions)
 __device__ __forceinline__ int eq4(u32x4 a, u32x4 b)
 {
     return (int)(a.x == b.x) + (int)(a.y == b.y) + (int)(a.z == b.z) + (int)(a.w == b.w);
