@@ -219,6 +219,32 @@ __device__ __forceinline__ EstimatorTables stage_tables(EstimatorLds &lds, const
     return t;
 }
 
+// The linear-counting table alone in LDS; raw / bias stay in global memory.  For kernels whose rows are nearly all in the
+// linear-counting range (a hop-1 row of fewer than 147 neighbours at p = 8): 1 KB of LDS per workgroup instead of 8.
+template <int M1>
+struct LcLds {
+    float lc[M1];
+};
+
+template <int M1>
+__device__ __forceinline__ EstimatorTables stage_lc_only(LcLds<M1> &lds, const ss_hll_params &prm)
+{
+    const int m1 = (1 << prm.p) + 1;
+    const bool lc_in_lds = m1 <= M1;
+    if (lc_in_lds)
+        for (int i = threadIdx.x; i < m1; i += blockDim.x) lds.lc[i] = prm.lc_table[i];
+    __syncthreads();
+    EstimatorTables t;
+    t.raw = prm.raw_est;
+    t.bias = prm.bias;
+    t.lc = lc_in_lds ? lds.lc : prm.lc_table;
+    t.n_tbl = prm.n_tbl;
+    t.lc_min_zeros = prm.lc_min_zeros;
+    t.alpha_mm = prm.alpha_mm;
+    t.five_m = 5.0f * (float)(1 << prm.p);
+    return t;
+}
+
 constexpr int kMegaSlot = SS_MEGA_SLOT_BYTES, kMegaHllOffset = 1024;
 
 // Cross-workgroup hand-off of the mega-row partials WITHOUT cache-wide fences: the 8 XCD L2s are not coherent with each

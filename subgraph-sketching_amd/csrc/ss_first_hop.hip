@@ -137,18 +137,21 @@ __global__ __launch_bounds__(256) void first_hop_rows_kernel(GraphArgs g, const 
 // HLL-only first hop, latency-optimised: one 16-lane DPP row per destination (4 destinations in flight per wave).
 // Used when the caller asks for the HLL sketch alone (the two-stream build runs the HLL chain beside the MinHash
 // chain); the one-row-per-wave kernel above is a single dependent chain per wave and takes 4x longer for this.
-constexpr int kHllRows = 4;
+constexpr int kHllRows = 4;  // (2, 6 and 8 measured the same 25 us on the bench graph: the kernel is not bound by its prefetch depth)
 
 __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, uint8_t *__restrict__ hll_out,
                                                             float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm,
                                                             bool skip_hubs)
 {
-    __shared__ EstimatorLds lds;
+    // only the linear-counting table is staged (this kernel is only launched for p = 8: 257 entries): a hop-1 row leaves the
+    // linear-counting range at 147 neighbours, and those few read raw / bias from global memory.  17 KB of LDS and 60 VGPRs
+    // instead of 24.5 KB and 73: 8 workgroups per CU instead of 6 (24.4-25.9 -> 22.9 us on the bench graph)
+    __shared__ LcLds<257> lds;
     __shared__ __attribute__((aligned(16))) uint32_t rows[256 / kRow][256];  // one u32 per register and 16-lane group
     const bool want_cards = cards_out != nullptr;
     report_hub_rows(g);
     EstimatorTables est;
-    if (want_cards) est = stage_tables(lds, prm);
+    if (want_cards) est = stage_lc_only(lds, prm);
     const int l = threadIdx.x & (kRow - 1);
     const int grp = threadIdx.x / kRow;
     // kHllRows rows per lane group, one after the other through the same LDS row image; the row bounds and the first
