@@ -40,6 +40,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 from argparse import Namespace
 from ctypes import byref, c_float, c_int32
@@ -314,6 +315,7 @@ def main():
     ap.add_argument('--sustain-seconds', type=float, default=8.0,
                     help='length of the sustained run after the timed region (0 = skip); long enough for a 5 s utilisation sampler')
     ap.add_argument('--strong-peer', action='store_true', help='N > 1: add the peer-write build to the strong-scaling figures (maps peers\' memory through CUDA-IPC)')
+    ap.add_argument('--strong-timeout', type=float, default=150.0, help='N > 1: seconds the strong-scaling figures may take before the line is printed without them')
     ap.add_argument('--no-strong', action='store_true', help='N > 1: skip the strong-scaling figures measured after the timed region')
     ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` shapes measured after the timed region')
     ap.add_argument('--no-kernel-table', action='store_true', help='skip the per-kernel HIP-event table (extra steps after the timed region)')
@@ -580,10 +582,23 @@ def main():
     # precompute of the config (one build + its link set) and one build + one global batch; with the build replicated and
     # row-sharded (exchange form chosen by dist.choose_exchange's micro-probe).  speedup_vs_n1_same_work = t(1 GPU) / t(N GPUs).
     if launched and world > 1 and a.api == 'build_query' and not a.no_strong:
+        # The figures below run collectives that the timed region does not (row exchanges, feature all-gathers).  A rank that
+        # fails alone would leave the others waiting in one for ever, and the weak line above is already measured: a watchdog
+        # prints it without the figures and ends the process if they take longer than --strong-timeout.
+        def bail():
+            if rank == 0:
+                out['strong'] = {'error': f'strong-scaling figures did not finish within {a.strong_timeout:.0f} s; skipped'}
+                out['cpu_baseline'] = None
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(a.strong_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             out['strong'] = strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank, with_peer=a.strong_peer)
         except Exception as exc:  # (deterministic failures are the same on every rank; the headline line must survive)
             out['strong'] = {'error': f'{type(exc).__name__}: {exc}'}
+        watchdog.cancel()
     default_line = a.config == 'collab' and a.graph == 'uniform' and a.api == 'build_query' and batch == cfg['batch']
     feats_host = feats.cpu().numpy() if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
     if rank == 0 and world == 1 and not a.no_secondary and default_line:
