@@ -37,9 +37,17 @@ while time.time() - t0 < seconds:
     H.HUB_THRESHOLD = int(rng.choice([0, 0, 8, 40, 300])) or None
     B = int(rng.choice([1, 17, 400, 5000]))
     links = rng.randint(-n, n, size=(B, 2)).astype(np.int64)
+    style = int(rng.randint(4))  # link lists with locality: the grouped / run-aware query paths (round 3)
+    if style == 1:
+        links = links[np.argsort(links[:, 0], kind='stable')]
+    elif style == 2:  # evaluation style: every source lists its pairs together
+        links[:, 0] = np.repeat(rng.randint(-n, n, size=B // 7 + 1), 7)[:B]
+    H.GROUP_LINKS_MIN = int(rng.choice([1, 1, 1 << 20]))          # 1: every query of this trial takes the grouped path
+    H.GROUP_GATHER_MIN = int(rng.choice([1, 1 << 24]))            # 1: ... through the gather / scatter passes
     eh = ssa.ElphHashes(Namespace(max_hash_hops=h, hll_p=8, minhash_num_perm=128, floor_sf=bool(rng.randint(2)), use_zero_one=bool(rng.randint(2))))
     eh.hll_tables = t8
-    tag = f'n={n} e_dir={ei.shape[1]} h={h} B={B} hub={H.HUB_THRESHOLD}'
+    eh.group_links = [True, False, 'auto'][rng.randint(3)]
+    tag = f'n={n} e_dir={ei.shape[1]} h={h} B={B} hub={H.HUB_THRESHOLD} links={style} group={eh.group_links}/{H.GROUP_LINKS_MIN}/{H.GROUP_GATHER_MIN}'
     otab, ocards = oracle.build_hash_tables(n, ei, h, 128, prm)
     lk_pos = np.where(links < 0, links + n, links)
     ofeat = oracle.pair_features(lk_pos, otab, ocards, h, prm, use_zero_one=eh.use_zero_one, floor_sf=eh.floor_sf)
@@ -50,7 +58,7 @@ while time.time() - t0 < seconds:
     for k in range(1, h + 1):
         ok &= np.array_equal(table[k].mh_u32.cpu().numpy().view(np.uint32), otab[k]['minhash'])
         ok &= np.array_equal(table[k].hll_u8.cpu().numpy(), otab[k]['hll'])
-    f1 = eh.get_subgraph_features(tlk, table, cards)
+    f1 = eh.get_subgraph_features(tlk, table, cards, batch_size=int(rng.choice([11000000, 1000, 64])))
     scale = max(1.0, float(np.abs(ofeat).max()) / 100) if ofeat.size else 1.0
     ok &= bool(np.allclose(f1.cpu().numpy(), ofeat, rtol=1e-4, atol=1e-4 * scale))
     # ELPH style (explicit self loops over max(edge_index) + 1 nodes, per-hop modules, deferred launches)
@@ -66,6 +74,29 @@ while time.time() - t0 < seconds:
         ok &= torch.equal(f2, f1)
         for k in range(1, h + 1):  # whoever asks afterwards gets the whole tables
             ok &= np.array_equal(H._packed_minhash_of(tb[k]['minhash'], dev).cpu().numpy().view(np.uint32), otab[k]['minhash'])
+    # the SAME engine on another graph of the same shape: hub hints and the content-keyed CSR must not carry anything over
+    if ei.shape[1] and rng.randint(3) == 0:
+        top = int(ei.max())
+        e2 = rng.randint(0, top + 1, size=e.shape)
+        if rng.randint(2):  # this one skewed whatever the first was (a stale "no hub rows" hint)
+            e2[0] = np.minimum(((top + 1) * rng.random_sample(e.shape[1]) ** 3).astype(np.int64), top)
+        e2[:, 0] = top  # (same max id: the ELPH-style edge_index keeps its shape)
+        ei2 = np.concatenate([e2, e2[::-1]], axis=1).astype(np.int64)
+        otab2, ocards2 = oracle.build_hash_tables(n, ei2, h, 128, prm)
+        tei2 = torch.from_numpy(ei2).to(dev)
+        for rep in range(2):  # (the second build runs on the first one's hint)
+            table2, cards2 = eh.build_hash_tables(n, tei2)
+            for k in range(1, h + 1):
+                ok &= np.array_equal(table2[k].mh_u32.cpu().numpy().view(np.uint32), otab2[k]['minhash'])
+                ok &= np.array_equal(table2[k].hll_u8.cpu().numpy(), otab2[k]['hll'])
+            ok &= bool(np.allclose(cards2.cpu().numpy(), ocards2, rtol=1e-4, atol=1e-4))
+        # ELPH style: the tensor of the first graph edited in place (same allocation, same shape, new contents)
+        hei[:, :tei2.size(1)] = tei2
+        tb = {0: {'minhash': eh.initialise_minhash(n), 'hll': eh.initialise_hll(n)}}
+        for k in range(1, h + 1):
+            tb[k] = {'hll': eh.hll_prop(tb[k - 1]['hll'], hei), 'minhash': eh.minhash_prop(tb[k - 1]['minhash'], hei)}
+            ok &= np.array_equal(tb[k]['hll'].cpu().numpy().view(np.uint8), otab2[k]['hll'])
+            ok &= np.array_equal(H._packed_minhash_of(tb[k]['minhash'], dev).cpu().numpy().view(np.uint32), otab2[k]['minhash'])
     eh.check_errors()
     trials += 1
     if not ok:
