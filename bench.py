@@ -198,6 +198,16 @@ def secondary_case(ssa, dev, name, config, graph='uniform', alpha=0.5, api='buil
     eh.check_errors()
     per_launch = links.size(0) if api == 'buddy' and links.size(0) <= 11000000 else batch
     bytes_ = rf.kernel_bytes(n, e_dir + (n if api == 'elph' else 0), P, HLL_P, h, per_launch, hub_e, hub_n)[family]
+    survey = None
+    H = ssa.hashing
+    if api == 'buddy' and H.GROUP_LINKS_MIN and links.size(0) >= H.GROUP_LINKS_MIN and links.size(0) <= 11000000:
+        # the precompute walks its links grouped by their first node: that node's rows are fetched once per run of pairs, not
+        # once per pair -- the roofline fraction is taken on the bytes this walk has to move; the 2h-rows-per-pair figure of
+        # SURVEY 8(d) (which such a walk beats by construction: 1.18 "of peak" at this size) is kept beside it
+        runs = int(torch.unique(links[:, 0]).numel())
+        survey = {'bytes': bytes_, 'frac_of_hbm_peak': bytes_ / (dom_ms.value * 1e-3) / 1e9 / rf.HBM_PEAK_GBS if dom_ms.value else None,
+                  'note': '2h table rows per pair (SURVEY 8(d)); the grouped walk fetches the first node\'s rows once per run'}
+        bytes_ = rf.pair_bytes_grouped(links.size(0), runs, P, HLL_P, h)
     frac = bytes_ / (dom_ms.value * 1e-3) / 1e9 / rf.HBM_PEAK_GBS if dom_ms.value else None
     table_bytes = rf.gathered_table_bytes(n, family, P, HLL_P, h)
     return {'name': name, 'config': config, 'graph': graph if graph == 'uniform' else f'{graph} (endpoint weights ~ rank^-{alpha})',
@@ -208,6 +218,7 @@ def secondary_case(ssa, dev, name, config, graph='uniform', alpha=0.5, api='buil
             'hub_rows': hub_n, 'hub_edge_share': hub_e / e_dir,
             'resident': 'infinity-cache' if table_bytes <= rf.INFINITY_CACHE_BYTES else 'hbm',
             'cache_resident_fraction': rf.cache_resident_fraction(table_bytes),
+            **({'survey_definition': survey, 'source_runs': runs} if survey else {}),
             **({'note': 'above 1: algorithmic bytes count one row read per in-edge; on this skewed graph the sources of the regular '
                         'rows\' in-edges repeat (endpoint weights ~ rank^-alpha) and a cache-resident table serves the repeats from '
                         'the L2 / Infinity Cache -- more bytes reach the CUs than HBM could deliver, none are skipped (every row '

@@ -69,6 +69,15 @@ def pair_bytes(P=128, p=8, h=2):
     return 2 * h * (4 * P + (1 << p)) + 16 + 8 * h + 4 * h * (h + 2)
 
 
+def pair_bytes_grouped(pairs, runs, P=128, p=8, h=2):
+    """bytes of a query over `pairs` links walked grouped by their first node (ss_pair_features_grouped, hashing.GROUP_LINKS_MIN):
+    the first node's h rows are fetched once per RUN of pairs that share it (`runs` = distinct first nodes of a grouped list),
+    everything else per pair as in pair_bytes -- the bytes the implemented walk has to move; pairs * pair_bytes() is the
+    SURVEY 8(d) definition, which charges 2h rows to every pair"""
+    R = 4 * P + (1 << p)
+    return pairs * (h * R + 16 + 8 * h + 4 * h * (h + 2)) + runs * h * R
+
+
 def step_bytes_implemented(N, E, P=128, p=8, h=2, B=65536, hub_edges=0, hub_rows=0):
     """bytes of one step under the implemented schedule: CSR build, hop 1 from node ids, h - 1 table hops, one query batch
     (the hub passes included: the same rows and edges, walked by other launches)"""

@@ -257,6 +257,9 @@ def test_byte_model_of_the_step(ssa):
     assert k['minhash_hop'] == (ep + n) * 512 + 4 * e + 8 * (n + 1)
     assert k['hll_hop'] == (ep + n) * 256 + 4 * e + 8 * (n + 1) + 4 * n
     assert k['pair_features'] == 65536 * 3136 and rf.pair_bytes(128, 8, 3) == 4708 and rf.pair_bytes(128, 8, 1) == 1572
+    # grouped walk: the first node's h rows once per run -- one run per pair is the per-pair definition again
+    assert rf.pair_bytes_grouped(1000, 1000, 128, 8, 2) == 1000 * 3136
+    assert rf.pair_bytes_grouped(1000, 10, 128, 8, 2) == 1000 * (3136 - 2 * 768) + 10 * 2 * 768
     assert abs(k['minhash_hop'] - 1.4611e9) < 5e6                   # 1.461 GB per launch
     survey = rf.step_bytes_survey(n, e, 128, 8, 2, 65536)
     assert abs(survey - (2 * 2.187e9 + 0.2055e9)) < 2e7             # 4.58 GB per step by SURVEY 8(d)
