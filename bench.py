@@ -91,9 +91,10 @@ def cpu_baseline(ei, links, n, h, batch):
                            lc_table=ssa.hashing.linear_counting_table(1 << t.p).numpy())
     cores = os.cpu_count()
     oracle.lib()
-    reps = 5 if n > 100000 else 50
-    t_build = t_query = 0.0
-    for _ in range(reps):
+    # a bounded sample of the same workload: full steps until ~10 s of CPU time have gone by (at least 5, at most 200 steps)
+    reps, t_build, t_query = 0, 0.0, 0.0
+    while reps < 5 or (t_build + t_query < 10.0 and reps < 200):
+        reps += 1
         t0 = time.perf_counter()
         rowptr, col = oracle.csr_build(n, ei)
         n_self = int(ei.max()) + 1
