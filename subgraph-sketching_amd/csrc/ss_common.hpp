@@ -245,6 +245,39 @@ __device__ __forceinline__ EstimatorTables stage_lc_only(LcLds<M1> &lds, const s
     return t;
 }
 
+// A compact image for kernels that are tight on LDS: LC entries of the linear-counting table and TBL entries of raw / bias; a
+// table that does not fit stays in global memory (datasketch ships 200 entries for p = 8; SS_MAX_TABLE = 512 is the ABI's bound).
+template <int LC, int TBL>
+struct CompactEstimatorLds {
+    float raw[TBL];
+    float bias[TBL];
+    float lc[LC];
+};
+
+template <int LC, int TBL>
+__device__ __forceinline__ EstimatorTables stage_tables_compact(CompactEstimatorLds<LC, TBL> &lds, const ss_hll_params &prm)
+{
+    const int m1 = (1 << prm.p) + 1;
+    const bool tbl_in_lds = prm.n_tbl <= TBL, lc_in_lds = m1 <= LC;
+    if (tbl_in_lds)
+        for (int i = threadIdx.x; i < prm.n_tbl; i += blockDim.x) {
+            lds.raw[i] = prm.raw_est[i];
+            lds.bias[i] = prm.bias[i];
+        }
+    if (lc_in_lds)
+        for (int i = threadIdx.x; i < m1; i += blockDim.x) lds.lc[i] = prm.lc_table[i];
+    __syncthreads();
+    EstimatorTables t;
+    t.raw = tbl_in_lds ? lds.raw : prm.raw_est;
+    t.bias = tbl_in_lds ? lds.bias : prm.bias;
+    t.lc = lc_in_lds ? lds.lc : prm.lc_table;
+    t.n_tbl = prm.n_tbl;
+    t.lc_min_zeros = prm.lc_min_zeros;
+    t.alpha_mm = prm.alpha_mm;
+    t.five_m = 5.0f * (float)(1 << prm.p);
+    return t;
+}
+
 constexpr int kMegaSlot = SS_MEGA_SLOT_BYTES, kMegaHllOffset = 1024;
 
 // Cross-workgroup hand-off of the mega-row partials WITHOUT cache-wide fences: the 8 XCD L2s are not coherent with each

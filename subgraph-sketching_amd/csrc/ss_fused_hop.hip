@@ -32,8 +32,8 @@ namespace ss {
 
 constexpr int kFusedRows = 4;
 #ifndef SS_HLL_INFLIGHT
-#define SS_HLL_INFLIGHT 11
-#define SS_HLL_LDS 5
+#define SS_HLL_INFLIGHT 7
+#define SS_HLL_LDS 7
 #endif
 constexpr int kHllInFlight = SS_HLL_INFLIGHT;
 
@@ -99,17 +99,19 @@ __device__ __forceinline__ void hll_fold(const HllPosted &h, u32x4 &ae, u32x4 &a
 // row's next four neighbours) covered 24 neighbours but cost 157-167 VGPRs (three wavefronts per SIMD): 181-196 us; a single re-post of
 // 8 chunks before the last MinHash row (coverage 16, 134 VGPRs): 184 us.  Not shipped: the kernel lives on its fourth wavefront.
 template <int PPL>
-__global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
-                                                                   uint32_t *__restrict__ mh_out, int p, const uint8_t *__restrict__ hll_in,
-                                                                   uint8_t *__restrict__ hll_out, float *__restrict__ cards_out,
-                                                                   int64_t cards_stride, ss_hll_params prm, bool skip_hubs)
+__device__ __forceinline__ void fused_hop_body(const GraphArgs &g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
+                                               uint32_t *__restrict__ mh_out, int p, const uint8_t *__restrict__ hll_in,
+                                               uint8_t *__restrict__ hll_out, float *__restrict__ cards_out, int64_t cards_stride,
+                                               const ss_hll_params &prm, bool skip_hubs)
 {
     constexpr int R = kFusedRows, kNb = kWave - R;
-    __shared__ EstimatorLds lds;
+    // 3 KB of estimator tables (the kernel is p = 8 only: 257 linear-counting entries; raw / bias up to 256 entries, longer tables stay
+    // in global memory) + 7 KB of landings per wavefront = 31 KB: five workgroups per CU
+    __shared__ CompactEstimatorLds<257, 256> lds;
     __shared__ __attribute__((aligned(16))) uint8_t landing[256 / kWave][kHllLds > 0 ? kHllLds : 1][1024];
     const bool want_cards = cards_out != nullptr;
     EstimatorTables est = {};
-    if (want_cards) est = stage_tables(lds, prm);
+    if (want_cards) est = stage_tables_compact(lds, prm);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const uint32_t lds_wave = (uint32_t)(uintptr_t)&landing[wave][0][0];  // LDS byte address (low half of the generic pointer)
     const int64_t n_chunks = (g.rows() + R - 1) / R;
@@ -193,6 +195,17 @@ __global__ __launch_bounds__(256) void fused_hop_persistent_kernel(GraphArgs g, 
     }
 }
 
+// P = 64 / 128: the register allocator is held to 96 VGPRs (amdgpu_waves_per_eu: at least FIVE wavefronts per SIMD; it gets there
+// without scratch -- left alone it spreads to ~125 and four wavefronts).  P = 192 / 256 would spill at 96 and keep the default budget.
+template <int PPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PPL <= 2 ? 5 : 1))) void fused_hop_persistent_kernel(
+    GraphArgs g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb, uint32_t *__restrict__ mh_out, int p,
+    const uint8_t *__restrict__ hll_in, uint8_t *__restrict__ hll_out, float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm,
+    bool skip_hubs)
+{
+    fused_hop_body<PPL>(g, pa, pb, mh_out, p, hll_in, hll_out, cards_out, cards_stride, prm, skip_hubs);
+}
+
 }  // namespace ss
 
 extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, const uint64_t *b, int32_t P, uint32_t *mh1_out,
@@ -232,10 +245,13 @@ extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, 
     }
     constexpr int rows_per_block = 4 * kFusedRows;
     const unsigned blocks = (unsigned)((g.rows() + rows_per_block - 1) / rows_per_block);
-    // 4 workgroups are resident per CU (126 VGPRs); three times that many balance the tail (bench graph: 4 / 8 / 12 / 16 / all
-    // 14 742 workgroups: 158.7 / 153-157 / 150-153 / 153.5 / 163 us)
+    // 5 workgroups are resident per CU; several times that many balance the tail.  Bench graph (58 blocks per CU): 12 / 15 / 20 / 25 / 30 /
+    // 40 per CU: 148.7 / 147.8 / 146.2-146.9 / 149.9 / 149.2 / 151.2 us.  ppa / citation2 size (140 / 715 blocks per CU): 15 / 20 / 30 /
+    // 48 / 64 / 100 / 200 / all: 1 832 / 1 819 / 1 774 / 1 724 / 1 738 / 1 728 / 1 751 / 1 748 us and 3 540 / 3 499 / 3 448 / 3 418 / 3 408 /
+    // 3 419 / 3 457 / 3 814 us
     static const int wg_per_cu_env = getenv("SS_FUSED_WG_PER_CU") ? atoi(getenv("SS_FUSED_WG_PER_CU")) : 0;
-    static const int wg_per_cu = (wg_per_cu_env > 0 && wg_per_cu_env <= 64) ? wg_per_cu_env : 12;  // (a bad value falls back to the default)
+    const int wg_per_cu = (wg_per_cu_env > 0 && wg_per_cu_env <= 4096) ? wg_per_cu_env  // (a bad value falls back to the default)
+                          : (blocks > 256u * 128u ? 64 : 20);
     const unsigned grid = blocks < (unsigned)(256 * wg_per_cu) ? blocks : (unsigned)(256 * wg_per_cu);
     {
         ProfileSpan span(s, SS_PROF_FUSED);

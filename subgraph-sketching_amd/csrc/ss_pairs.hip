@@ -133,8 +133,13 @@ __device__ __forceinline__ void assemble_features(const float (&I)[H][H], const 
 
 // TP, TM > 0: compile-time sketch sizes, all 2H rows register-resident (fast path).
 // TP = TM = 0: run-time sizes, rows re-read per (k1,k2) (parameter sweeps / tests; not tuned).
+// Occupancy: left alone the register allocator takes 117 (h = 2) / 151 (h = 3) VGPRs at P = 128 -- four / three wavefronts per SIMD.
+// Held to five / four (96 / 128 VGPRs, 20 / 12 bytes of scratch) the kernel is unchanged at B = 65 536 and 5-7 % faster on link sets of
+// millions (collab-size BUDDY precompute 809-813 -> 771 us, citation2-size evaluation lists 4 267-4 297 -> 3 962 us per 8 M links);
+// six / five wavefronts spill in earnest (+25 %).  Only for P <= 128: the wider kernels would spill at these budgets.
 template <int H, int TP, int TM>
-__global__ __launch_bounds__(256) void pair_features_kernel(const int64_t *__restrict__ links, int64_t B, int64_t N, PairTables tabs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TP > 0 && TP <= 128) ? (H == 2 ? 5 : H == 3 ? 4 : 1) : 1)))
+void pair_features_kernel(const int64_t *__restrict__ links, int64_t B, int64_t N, PairTables tabs,
                                                             int P_rt, int M_rt, const float *__restrict__ cards, int64_t cards_stride,
                                                             ss_hll_params prm, uint32_t flags, float *__restrict__ out,
                                                             int32_t *__restrict__ dbg_match, int32_t *__restrict__ dbg_zero,
