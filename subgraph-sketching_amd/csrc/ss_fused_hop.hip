@@ -20,9 +20,9 @@
 // Mapping: a wavefront owns kFusedRows = 4 consecutive destination rows.  MinHash side: as first_hop_rows_kernel (with 4 rows the
 // 60 col entries of a batch almost always cover the whole chunk: a batch reload in the middle of the walk would have to wait for
 // its ids with vmcnt(0) -- vmcnt retires in order -- and so for every HLL row posted before it).  HLL side: one 16-lane DPP row
-// per destination (lane c = 16-byte chunk c of the 256-byte row); the first kHllInFlight = 11 neighbour chunks per lane are
-// requested into registers up front and the next kHllLds = 5 into LDS (global_load_lds_dwordx4; ids by one coalesced load per
-// lane group, handed out by DPP row_newbcast), the rest of rows longer than 16 after the MinHash walk (hll_row16_finish).  Hub rows are skipped by both sides and
+// per destination (lane c = 16-byte chunk c of the 256-byte row); the first kHllInFlight = 7 neighbour chunks per lane are
+// requested into registers up front and the next kHllLds = 7 into LDS (global_load_lds_dwordx4; ids by one coalesced load per
+// lane group, handed out by DPP row_newbcast), the rest of rows longer than 14 after the MinHash walk (hll_row16_finish).  Hub rows are skipped by both sides and
 // served by the two hub kernels afterwards.  P = 64 * PPL, M = 256 (p = 8) only -- the shapes ss_first_hop has a kernel for.
 #include <cstdlib>
 
@@ -85,7 +85,7 @@ __device__ __forceinline__ void hll_fold(const HllPosted &h, u32x4 &ae, u32x4 &a
 }
 
 // ---- the kernel: persistent, software-pipelined -------------------------------------------------------------------------------
-// At ~125 VGPRs only four wavefronts share a SIMD, too few to hide the three dependent round trips at the head of a chunk (row
+// Four or five wavefronts per SIMD are too few to hide the three dependent round trips at the head of a chunk (row
 // bounds -> neighbour ids -> HLL rows): a one-chunk-per-wavefront form of this kernel gained 6 % over the two separate launches
 // (174 us against 184).  Here a wavefront keeps walking chunks (chunk = kFusedRows rows; chunk q, q + waves, ...) and the loads of the NEXT chunks are posted
 // before the MinHash walk of the current one:
@@ -97,7 +97,11 @@ __device__ __forceinline__ void hll_fold(const HllPosted &h, u32x4 &ae, u32x4 &a
 // ~100-120 us: what is left are the loads of rows with more than 16 neighbours, issued and awaited after the walk.  Register-only
 // attempts at more coverage: a rolling window (fold four posted chunks after every MinHash row and re-post their registers with the
 // row's next four neighbours) covered 24 neighbours but cost 157-167 VGPRs (three wavefronts per SIMD): 181-196 us; a single re-post of
-// 8 chunks before the last MinHash row (coverage 16, 134 VGPRs): 184 us.  Not shipped: the kernel lives on its fourth wavefront.
+// 8 chunks before the last MinHash row (coverage 16, 134 VGPRs): 184 us.  Not shipped: the kernel lives on its occupancy.
+// Round 3: 11 register + 5 LDS landings at ~125 VGPRs (four wavefronts per SIMD) was 151-152 us; held to 96 VGPRs by
+// amdgpu_waves_per_eu (no scratch) with 7 + 7 landings and a 3 KB estimator image (31 KB of LDS: five workgroups per CU) it is
+// 146 us -- and 1 946 -> 1 730 / 3 650 -> 3 410 us at ppa / citation2 size, where the table hop's gathers come from HBM and a fifth
+// wavefront hides more of them.  (6 + 7, 7 + 6: the same within noise; 4 + 6: 154-158 us -- coverage still matters; six wavefronts spill.)
 template <int PPL>
 __device__ __forceinline__ void fused_hop_body(const GraphArgs &g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
                                                uint32_t *__restrict__ mh_out, int p, const uint8_t *__restrict__ hll_in,

@@ -340,7 +340,7 @@ __device__ __forceinline__ bool first_hop_minhash_fast(const int32_t *__restrict
 // two-phase evaluation (first_hop_minhash_fast above), evaluates the winner exactly and stores the row.  Rows flagged
 // ambiguous (and rows that list themselves: duplicates of the implicit self loop) are redone by the exact walk.
 // MIR: rows also go to the peers' tables (peer-write build); a compile-time switch -- the store loop and the pointer it needs
-// cost first_hop_rows_kernel 14 registers and fused_hop_persistent_kernel its fourth wavefront per SIMD
+// cost first_hop_rows_kernel 14 registers and fused_hop_persistent_kernel a wavefront per SIMD
 template <int PPL, int R, bool MIR = false>
 struct MinhashRows {
     static constexpr int P = PPL * kWave;
