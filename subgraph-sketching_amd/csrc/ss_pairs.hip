@@ -133,12 +133,14 @@ __device__ __forceinline__ void assemble_features(const float (&I)[H][H], const 
 
 // TP, TM > 0: compile-time sketch sizes, all 2H rows register-resident (fast path).
 // TP = TM = 0: run-time sizes, rows re-read per (k1,k2) (parameter sweeps / tests; not tuned).
-// Occupancy: left alone the register allocator takes 117 (h = 2) / 151 (h = 3) VGPRs at P = 128 -- four / three wavefronts per SIMD.
-// Held to five / four (96 / 128 VGPRs, 20 / 12 bytes of scratch) the kernel is unchanged at B = 65 536 and 5-7 % faster on link sets of
-// millions (collab-size BUDDY precompute 809-813 -> 771 us, citation2-size evaluation lists 4 267-4 297 -> 3 962 us per 8 M links);
-// six / five wavefronts spill in earnest (+25 %).  Only for P <= 128: the wider kernels would spill at these budgets.
-template <int H, int TP, int TM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TP > 0 && TP <= 128) ? (H == 2 ? 5 : H == 3 ? 4 : 1) : 1)))
+// OCC (walks with locality, ss_pair_features_grouped: links grouped by their first node or listed that way): left alone the register
+// allocator takes 117 (h = 2) / 151 (h = 3) VGPRs at P = 128 -- four / three wavefronts per SIMD.  Held to five / four (96 / 128 VGPRs,
+// 20 / 12 bytes of scratch) the grouped walks are 5-7 % faster (collab-size BUDDY precompute 809-813 -> 771 us, citation2-size
+// evaluation lists 4 267-4 297 -> 3 962 us per 8 M links: the first node's rows come from the L2, a fifth wavefront hides more of what
+// is left); on uniformly random pairs the same budget is level to 9 % slower (HBM-resident tables, B = 262 144: 143 -> 157 us), so
+// ss_pair_features keeps the default budget; six / five wavefronts spill in earnest (+25 %).
+template <int H, int TP, int TM, bool OCC = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC ? (H == 2 ? 5 : H == 3 ? 4 : 1) : 1)))
 void pair_features_kernel(const int64_t *__restrict__ links, int64_t B, int64_t N, PairTables tabs,
                                                             int P_rt, int M_rt, const float *__restrict__ cards, int64_t cards_stride,
                                                             ss_hll_params prm, uint32_t flags, float *__restrict__ out,
@@ -507,7 +509,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAP ? (H ==
 template <int H, int TP, int TM>
 int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &tabs, int P, int M, const float *cards,
                  int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *dbg_match,
-                 int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream, const int32_t *order = nullptr)
+                 int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream, const int32_t *order = nullptr,
+                 bool grouped = false)
 {
     const int pairs_per_block = 256 / kRow;
     // pairs per 16-lane group the grid is sized for: ONE while that still fits the chip in a single round of workgroups (ELPH
@@ -526,8 +529,12 @@ int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &t
     if (blocks < 1) blocks = 1;
     {
         ProfileSpan span(stream, SS_PROF_PAIRS);
-        hipLaunchKernelGGL((pair_features_kernel<H, TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, links, B, N, tabs, P, M,
-                           cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees, order);
+        if (grouped && TP == 128 && H >= 2)  // (the default sketch shape only: one more instantiation per hop count)
+            hipLaunchKernelGGL((pair_features_kernel<H, TP, TM, (TP == 128 && H >= 2)>), dim3((unsigned)blocks), dim3(256), 0, stream, links, B, N,
+                               tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees, order);
+        else
+            hipLaunchKernelGGL((pair_features_kernel<H, TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, links, B, N, tabs, P, M,
+                               cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees, order);
     }
     SS_LAUNCH_CHECK();
     return SS_OK;
@@ -536,19 +543,20 @@ int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &t
 template <int H>
 int dispatch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &tabs, int P, int M, const float *cards,
                    int64_t cards_stride, const ss_hll_params &prm, uint32_t flags, float *out, int32_t *dbg_match,
-                   int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream, const int32_t *order = nullptr)
+                   int32_t *dbg_zero, float *dbg_inter, int32_t *err, const float *degrees, hipStream_t stream, const int32_t *order = nullptr,
+                   bool grouped = false)
 {
 #define SS_PAIRS_FAST(TP)                                                                                                      \
     if (P == TP && M == 256)                                                                                                    \
         return launch_pairs<H, TP, 256>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero,     \
-                                        dbg_inter, err, degrees, stream, order);
+                                        dbg_inter, err, degrees, stream, order, grouped);
     SS_PAIRS_FAST(128)  // the reference's default shape
     SS_PAIRS_FAST(64)   // the other permutation counts the first hop is specialised for (ss_first_hop: P / 64 = 1 .. 4)
     SS_PAIRS_FAST(192)
     SS_PAIRS_FAST(256)
 #undef SS_PAIRS_FAST
     return launch_pairs<H, 0, 0>(links, B, N, tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter,
-                                 err, degrees, stream, order);
+                                 err, degrees, stream, order, grouped);
 }
 
 template <int H, int TP>
@@ -596,7 +604,7 @@ int dispatch_pair_runs(const int64_t *links, const int32_t *order, int64_t B, in
 static int pair_features_impl(const int64_t *links, int64_t B, int64_t N, int32_t h, const uint32_t *const *mh, int32_t P,
                               const uint8_t *const *hll, const float *cards, int64_t cards_stride, const ss_hll_params *prm,
                               uint32_t flags, const float *degrees, float *out, int32_t *dbg_match, int32_t *dbg_zero,
-                              float *dbg_inter, int32_t *err_flag, void *stream, const int32_t *order = nullptr)
+                              float *dbg_inter, int32_t *err_flag, void *stream, const int32_t *order = nullptr, bool grouped = false)
 {
     using namespace ss;
     if (h < 1 || h > SS_MAX_HOPS) return SS_ERR_UNSUPPORTED;  // hashing.py:54, 308-309
@@ -615,9 +623,9 @@ static int pair_features_impl(const int64_t *links, int64_t B, int64_t N, int32_
     const int M = 1 << prm->p;
     hipStream_t s = (hipStream_t)stream;
     switch (h) {
-        case 1: return dispatch_pairs<1>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s, order);
-        case 2: return dispatch_pairs<2>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s, order);
-        default: return dispatch_pairs<3>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s, order);
+        case 1: return dispatch_pairs<1>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s, order, grouped);
+        case 2: return dispatch_pairs<2>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s, order, grouped);
+        default: return dispatch_pairs<3>(links, B, N, tabs, P, M, cards, cards_stride, *prm, flags, out, dbg_match, dbg_zero, dbg_inter, err_flag, degrees, s, order, grouped);
     }
 }
 
@@ -724,7 +732,7 @@ static int pair_features_grouped_impl(int which /* -1: chosen per hop count, 0: 
     if (!runs) {
         if (order && B >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
         return pair_features_impl(links, B, N, h, mh, P, hll, cards, cards_stride, prm, flags, degrees, out, nullptr, nullptr, nullptr,
-                                  err_flag, stream, order);
+                                  err_flag, stream, order, /*grouped=*/true);
     }
     PairTables tabs = {};
     for (int k = 0; k < h; ++k) {

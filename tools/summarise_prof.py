@@ -34,7 +34,7 @@ if pmc:
         if 'propagate_kernel<128, 256>' in k and 'hub' not in k:
             hbm = 2 * v.get('FETCH_SIZE_KB_avg', 0) * 1024 + v.get('WRITE_SIZE_KB_avg', 0) * 1024
             out['propagate_kernel_hbm_bytes_per_launch'] = hbm
-        if 'pair_features_kernel<2, 128, 256>' in k:
+        if 'pair_features_kernel<2, 128, 256' in k:
             out['pair_features_kernel_hbm_bytes_per_launch'] = 2 * v.get('FETCH_SIZE_KB_avg', 0) * 1024 + v.get('WRITE_SIZE_KB_avg', 0) * 1024
     json.dump(out, open(os.path.join(root, 'profiles', f'{tag}_pmc.json'), 'w'), indent=1)
     if '--set-traffic' in sys.argv:
