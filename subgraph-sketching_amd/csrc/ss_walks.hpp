@@ -63,13 +63,36 @@ __device__ __forceinline__ u32x4 minhash_walk128(const uint32_t *__restrict__ mh
     const int head = total < kWave ? total : kWave;
     u32x4 acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     // one pair of neighbours per iteration, NOT batched: batches of 2 / 4 pairs (masked or clamped) measured 194-198 us
-    // against 187 us for this loop -- eight waves per SIMD already cover the latency, extra instructions only cost issue slots
+    // against 187 us for this loop -- eight waves per SIMD already cover the latency, extra instructions only cost issue slots.
+    // Round 3, all three shapes (SS_MH_BATCH = 1 / 2 / 3 / 4 pairs per iteration): collab size 191.4 / 193.1 / 196.2 / 199.4 us, ppa size
+    // 2 936 / 2 977 / 2 972 / 2 975 us, citation2 size (1.5 GB table, HBM-resident) 5 661 / 5 566-5 591 / 5 572-5 604 / 5 581-5 593 us:
+    // -1.5 % where the table lives in HBM, +1 % where it does not.  Not worth a second instantiation.
+#ifndef SS_MH_BATCH
+#define SS_MH_BATCH 1
+#endif
+#if SS_MH_BATCH == 1
     for (int t0 = 0; t0 < head; t0 += 2) {  // wave-uniform trip count
         const int s0 = __builtin_amdgcn_readlane(my_nb, t0), s1 = __builtin_amdgcn_readlane(my_nb, (t0 + 1) & (kWave - 1));
         const int t = t0 + sg;
         const int64_t j = t < deg ? (int64_t)(sg ? s1 : s0) : self_row;
         if (t < head) acc = min4(acc, *reinterpret_cast<const u32x4 *>(mh_in + j * 128 + 4 * c));
     }
+#else
+    for (int t0 = 0; t0 < head; t0 += 2 * SS_MH_BATCH) {  // wave-uniform trip count
+        u32x4 x[SS_MH_BATCH];
+#pragma unroll
+        for (int k = 0; k < SS_MH_BATCH; ++k) {
+            const int s0 = __builtin_amdgcn_readlane(my_nb, (t0 + 2 * k) & (kWave - 1));
+            const int s1 = __builtin_amdgcn_readlane(my_nb, (t0 + 2 * k + 1) & (kWave - 1));
+            const int t = t0 + 2 * k + sg;
+            const int64_t j = t < deg ? (int64_t)(sg ? s1 : s0) : self_row;
+            x[k] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (t < head) x[k] = *reinterpret_cast<const u32x4 *>(mh_in + j * 128 + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < SS_MH_BATCH; ++k) acc = min4(acc, x[k]);
+    }
+#endif
     if (total > kWave) acc = min4(acc, minhash_walk(mh_in, nb, deg, total, self_row, kWave + sg, 2, 128, c));
     return acc;
 }
