@@ -1164,11 +1164,33 @@ __global__ __launch_bounds__(256) void fingerprint_kernel(const int64_t *__restr
 {
     __shared__ unsigned long long red[2][256 / kWave];
     unsigned long long a = 0, b = 0;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t s = (uint64_t)src[e], d = (uint64_t)dst[e];
-        a += hash_u64(s * 0x9E3779B97F4A7C15ULL + d + 0x632BE59BD9B4E019ULL);
-        b += hash_u64((d ^ 0xD6E8FEB86659FD93ULL) * 0xC2B2AE3D27D4EB4FULL + s);
+    // per edge: one 64-bit mix m of (src, dst) -- injective in (s, d) for ids below 2^32 before the finaliser -- summed as is and
+    // summed once more through a second multiply-xorshift (two sums of different functions of m: an edit has to preserve both).
+    // Two edges per lane and load (16-byte loads of both rows), two such loads in flight: 11.3 -> 7 us for 2.6 M edges
+    auto add = [&](uint64_t sv, uint64_t dv) {
+        const uint64_t m = hash_u64(sv * 0x9E3779B97F4A7C15ULL + dv + 0x632BE59BD9B4E019ULL);
+        a += m;
+        uint64_t m2 = (m ^ (m >> 29)) * 0xC2B2AE3D27D4EB4FULL;
+        b += m2 ^ (m2 >> 32);
+    };
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int64_t pairs = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) ? 0 : E / 2;  // 16-byte aligned rows only
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64x2 *src2 = reinterpret_cast<const u64x2 *>(src), *dst2 = reinterpret_cast<const u64x2 *>(dst);
+    for (; q + stride < pairs; q += 2 * stride) {
+        const u64x2 s0 = src2[q], d0 = dst2[q], s1 = src2[q + stride], d1 = dst2[q + stride];
+        add(s0.x, d0.x);
+        add(s0.y, d0.y);
+        add(s1.x, d1.x);
+        add(s1.y, d1.y);
     }
+    for (; q < pairs; q += stride) {
+        const u64x2 s0 = src2[q], d0 = dst2[q];
+        add(s0.x, d0.x);
+        add(s0.y, d0.y);
+    }
+    for (int64_t e = 2 * pairs + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) add((uint64_t)src[e], (uint64_t)dst[e]);
     for (int off = kWave / 2; off > 0; off >>= 1) {
         a += __shfl_xor(a, off);
         b += __shfl_xor(b, off);
