@@ -291,6 +291,8 @@ __device__ __forceinline__ void block_range(const PassArgs &a, int64_t &lo, int6
         part = blockIdx.x % a.parts;
         parts = a.parts;
         const int64_t s = (int64_t)a.seg_base[group], e = (int64_t)a.seg_base[group + 1];
+        // (shares rounded up to whole tiles -- a 1.27-tile share sorts a tile that is a quarter full -- measured: ppa size 820 -> 831 us,
+        // citation2 size level; the extra workgroups matter more than the short runs)
         const int64_t per = (e - s + a.parts - 1) / a.parts;
         lo = s + per * part;
         if (lo > e) lo = e;
