@@ -12,6 +12,7 @@
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // rows_per_item rows gathered per 32-lane group, `items` groups in all (grid-stride)
+template <bool WRITE>
 __global__ __launch_bounds__(256) void gather_rows(const u32x4 *__restrict__ table, const int32_t *__restrict__ ids, int64_t items, int per_item,
                                                    u32x4 *__restrict__ out)
 {
@@ -20,6 +21,7 @@ __global__ __launch_bounds__(256) void gather_rows(const u32x4 *__restrict__ tab
     u32x4 acc = {~0u, ~0u, ~0u, ~0u};
     for (int64_t it = group0; it < items; it += stride) {
         const int32_t *my = ids + it * per_item;
+        if (WRITE) acc = u32x4{~0u, ~0u, ~0u, ~0u};
         for (int k = 0; k < per_item; k += 12) {  // 12 row loads in flight per lane before the first min
             u32x4 v[12];
 #pragma unroll
@@ -29,20 +31,23 @@ __global__ __launch_bounds__(256) void gather_rows(const u32x4 *__restrict__ tab
                 acc.x = min(acc.x, v[u].x); acc.y = min(acc.y, v[u].y); acc.z = min(acc.z, v[u].z); acc.w = min(acc.w, v[u].w);
             }
         }
+        if (WRITE) out[it * 32 + lane] = acc;  // the item's own 512-byte output row
     }
-    if (acc.x == 12345u) out[threadIdx.x] = acc;  // (never true: keeps the loads alive)
+    if (!WRITE && acc.x == 12345u) out[threadIdx.x] = acc;  // (never true: keeps the loads alive)
 }
 
 int main()
 {
-    const int per_item = 12;                  // neighbours per destination row (collab-like: 11 + self)
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    u32x4 *out; hipMalloc(&out, 4096);
-    printf("%10s %14s\n", "table MB", "gather TB/s");
+    const int64_t n_items_max = 256ll << 10;
+    u32x4 *out; hipMalloc(&out, n_items_max * 512);
+    printf("%10s %9s %6s %14s\n", "table MB", "rows/item", "write", "TB/s (gathers + output rows)");
+    for (int per_item : {12, 24})
+    for (int write = 0; write < 2; ++write)
     for (double mb : {30.0, 60.0, 120.0, 200.0, 295.0, 600.0, 1500.0}) {
         const int64_t rows = (int64_t)(mb * 1e6 / 512);
-        const int64_t n_items = 256ll << 10;             // 256 Ki x 12 x 512 B = 1.6 GB per launch (the collab-size hop moves 1.46 GB)
+        const int64_t n_items = n_items_max;             // 256 Ki x 12 x 512 B = 1.6 GB per launch (the collab-size hop moves 1.46 GB)
         u32x4 *table; int32_t *ids;
         hipMalloc(&table, rows * 512); hipMemset(table, 1, rows * 512);
         std::vector<int32_t> h(n_items * per_item);
@@ -53,12 +58,13 @@ int main()
         float best_g = 1e9f;
         for (int rep = 0; rep < 6; ++rep) {
             hipEventRecord(e0);
-            gather_rows<<<grid, 256>>>(table, ids, n_items, per_item, out);
+            if (write) gather_rows<true><<<grid, 256>>>(table, ids, n_items, per_item, out);
+            else gather_rows<false><<<grid, 256>>>(table, ids, n_items, per_item, out);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (rep && ms < best_g) best_g = ms;
         }
-        printf("%10.0f %14.2f\n", mb, n_items * per_item * 512.0 / best_g / 1e9);
+        printf("%10.0f %9d %6d %14.2f\n", mb, per_item, write, n_items * (per_item + write) * 512.0 / best_g / 1e9);
         hipFree(table); hipFree(ids);
     }
     return 0;
