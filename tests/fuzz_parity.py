@@ -18,7 +18,7 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 dev = torch.device('cuda:0')
 H = ssa.hashing
 t8 = ssa.hll_tables.load(8, prefer='regenerated')
-prm = oracle.HllParams(t8.p, t8.threshold, t8.raw_estimate, t8.bias, alpha=t8.alpha, lc_table=H.linear_counting_table(256).numpy())
+prm8 = oracle.HllParams(t8.p, t8.threshold, t8.raw_estimate, t8.bias, alpha=t8.alpha, lc_table=H.linear_counting_table(256).numpy())
 rng = np.random.RandomState(int(os.environ.get('FUZZ_SEED', '12345')))
 t0, trials, bad = time.time(), 0, 0
 while time.time() - t0 < seconds:
@@ -44,11 +44,16 @@ while time.time() - t0 < seconds:
         links[:, 0] = np.repeat(rng.randint(-n, n, size=B // 7 + 1), 7)[:B]
     H.GROUP_LINKS_MIN = int(rng.choice([1, 1, 1 << 20]))          # 1: every query of this trial takes the grouped path
     H.GROUP_GATHER_MIN = int(rng.choice([1, 1 << 24]))            # 1: ... through the gather / scatter passes
-    eh = ssa.ElphHashes(Namespace(max_hash_hops=h, hll_p=8, minhash_num_perm=128, floor_sf=bool(rng.randint(2)), use_zero_one=bool(rng.randint(2))))
-    eh.hll_tables = t8
+    # a quarter of the trials: other sketch sizes (the run-time-sized kernels, the other specialised permutation counts)
+    P, hp = (int(rng.choice([4, 20, 64, 100, 192, 256, 260])), int(rng.choice([4, 5, 6, 8, 10, 12]))) if rng.randint(4) == 0 else (128, 8)
+    tp = t8 if hp == 8 else ssa.hll_tables.load(hp, prefer='regenerated')
+    prm = prm8 if hp == 8 else oracle.HllParams(tp.p, tp.threshold, tp.raw_estimate, tp.bias, alpha=tp.alpha,
+                                                 lc_table=H.linear_counting_table(1 << hp).numpy())
+    eh = ssa.ElphHashes(Namespace(max_hash_hops=h, hll_p=hp, minhash_num_perm=P, floor_sf=bool(rng.randint(2)), use_zero_one=bool(rng.randint(2))))
+    eh.hll_tables = tp
     eh.group_links = [True, False, 'auto'][rng.randint(3)]
-    tag = f'n={n} e_dir={ei.shape[1]} h={h} B={B} hub={H.HUB_THRESHOLD} links={style} group={eh.group_links}/{H.GROUP_LINKS_MIN}/{H.GROUP_GATHER_MIN}'
-    otab, ocards = oracle.build_hash_tables(n, ei, h, 128, prm)
+    tag = f'P={P} p={hp} n={n} e_dir={ei.shape[1]} h={h} B={B} hub={H.HUB_THRESHOLD} links={style} group={eh.group_links}/{H.GROUP_LINKS_MIN}/{H.GROUP_GATHER_MIN}'
+    otab, ocards = oracle.build_hash_tables(n, ei, h, P, prm)
     lk_pos = np.where(links < 0, links + n, links)
     ofeat = oracle.pair_features(lk_pos, otab, ocards, h, prm, use_zero_one=eh.use_zero_one, floor_sf=eh.floor_sf)
     ok = True
@@ -82,7 +87,7 @@ while time.time() - t0 < seconds:
             e2[0] = np.minimum(((top + 1) * rng.random_sample(e.shape[1]) ** 3).astype(np.int64), top)
         e2[:, 0] = top  # (same max id: the ELPH-style edge_index keeps its shape)
         ei2 = np.concatenate([e2, e2[::-1]], axis=1).astype(np.int64)
-        otab2, ocards2 = oracle.build_hash_tables(n, ei2, h, 128, prm)
+        otab2, ocards2 = oracle.build_hash_tables(n, ei2, h, P, prm)
         tei2 = torch.from_numpy(ei2).to(dev)
         for rep in range(2):  # (the second build runs on the first one's hint)
             table2, cards2 = eh.build_hash_tables(n, tei2)
