@@ -102,6 +102,9 @@ __device__ __forceinline__ void hll_fold(const HllPosted &h, u32x4 &ae, u32x4 &a
 // amdgpu_waves_per_eu (no scratch) with 7 + 7 landings and a 3 KB estimator image (31 KB of LDS: five workgroups per CU) it is
 // 146 us -- and 1 946 -> 1 730 / 3 650 -> 3 410 us at ppa / citation2 size, where the table hop's gathers come from HBM and a fifth
 // wavefront hides more of them.  (6 + 7, 7 + 6: the same within noise; 4 + 6: 154-158 us -- coverage still matters; six wavefronts spill.)
+// A second use of the register landings -- folded before the LAST MinHash row and sent out again for neighbours 14 .. 20 (ids from a
+// second id word per lane), coverage 21 -- needs the accumulators alive through that row's walk: 96 / 64 / 32 bytes of scratch with
+// 7 / 6 / 5 register landings and 197 / 177 / 154 us; with 4 (no scratch, coverage 15) 146 us, the same as without.  Not shipped.
 template <int PPL>
 __device__ __forceinline__ void fused_hop_body(const GraphArgs &g, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb,
                                                uint32_t *__restrict__ mh_out, int p, const uint8_t *__restrict__ hll_in,
