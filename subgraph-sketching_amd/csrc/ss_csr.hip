@@ -531,6 +531,7 @@ struct ContiguousEdges {
     const int2 *staged;
     unsigned long long seg_lo;
     uint32_t seg_n;
+    int node0;  // first node of the bucket: f(source, destination - node0)
     template <typename F>
     __device__ __forceinline__ void for_each(F &&f) const
     {
@@ -543,7 +544,7 @@ struct ContiguousEdges {
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (v[k].y >= 0) f(v[k]);
+                if (v[k].y >= 0) f(v[k].x, v[k].y - node0);
         }
     }
 };
@@ -559,6 +560,7 @@ struct GatheredEdges {
     int tiles;
     const uint16_t *long_tiles;  // LDS: tiles whose run is longer than kLongRun (listed by the kernel prologue) ...
     int n_long;                  // ... or 0 when there are none / too many to list (then every run is walked by its lane group)
+    int node0;                   // first node of the bucket: f(source, destination - node0)
     template <typename F>
     __device__ __forceinline__ void for_each(F &&f) const
     {
@@ -569,7 +571,10 @@ struct GatheredEdges {
             const int t = long_tiles[k];
             const uint32_t d = seg[t];
             const int2 *run = staged + (int64_t)t * kTile + (d & 0xFFFFu);
-            for (uint32_t q = threadIdx.x; q < (d >> 16); q += kFinishThreads) f(run[q]);
+            for (uint32_t q = threadIdx.x; q < (d >> 16); q += kFinishThreads) {
+                const int2 v = run[q];
+                f(v.x, v.y - node0);
+            }
         }
         for (int t0 = grp; t0 < tiles; t0 += 4 * kGroups) {  // four runs requested per lane group before the first is consumed
             int2 v[4];
@@ -583,15 +588,15 @@ struct GatheredEdges {
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (v[k].y >= 0) f(v[k]);
+                if (v[k].y >= 0) f(v[k].x, v[k].y - node0);
                 if (len[k] > (uint32_t)LANES) {  // the rest of a run longer than the lane group, two loads in flight
                     const int t = t0 + k * kGroups;
                     const int2 *run = staged + (int64_t)t * kTile + (seg[t] & 0xFFFFu);
                     for (uint32_t q = LANES + l; q < len[k]; q += 2 * LANES) {
                         const int2 a = run[q];
                         const int2 b = q + LANES < len[k] ? run[q + LANES] : make_int2(0, -1);
-                        f(a);
-                        if (b.y >= 0) f(b);
+                        f(a.x, a.y - node0);
+                        if (b.y >= 0) f(b.x, b.y - node0);
                     }
                 }
             }
@@ -599,11 +604,6 @@ struct GatheredEdges {
     }
 };
 
-struct FinishLds {
-    uint32_t cnt[1024], excl[1024 + 1];
-    int32_t image[kFinishCap];  // LDS image of (a node sub-range of) the bucket's col segment
-    uint32_t wave_tot[kFinishThreads / kWave];
-};
 
 // what the finish step writes besides col: rowptr and the hub / mega row lists
 struct RowOutputs {
@@ -659,6 +659,12 @@ __device__ __forceinline__ void scan_bucket_nodes(const uint32_t *cnt, uint32_t 
     if (threadIdx.x == 0) excl[nb] = seg_n;
 }
 
+struct FinishLds {
+    uint32_t cnt[1024], excl[1024 + 1];
+    int32_t image[kFinishCap];  // LDS image of (a node sub-range of) the bucket's col segment
+    uint32_t wave_tot[kFinishThreads / kWave];
+};
+
 // where the finish step registers the buckets it leaves to the dense launches
 struct DenseArgs {
     int32_t *count;         // [kDenseSyncInts], see above
@@ -666,41 +672,52 @@ struct DenseArgs {
     uint32_t *node_cnt;     // [dense bucket][1024]
     uint32_t *share_off;    // [share][1024]
     int helpers;            // helper workgroups appended to the finish launch (0: the dense steps are launches of their own)
+
+    // (workgroup-uniform, all threads) bucket blockIdx.x has seg_n > kDenseMin edges starting at col[seg_lo]
+    __device__ __forceinline__ void register_bucket(FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int nb) const
+    {
+        if (threadIdx.x == 0) {
+            const int shares = (int)((seg_n + kDensePart - 1) / kDensePart);
+            const int d = atomicAdd(&count[0], 1);
+            const int first = atomicAdd(&count[1], shares);
+            list[d] = DenseBucket{(int32_t)blockIdx.x, first, shares, seg_n, seg_lo};
+            lds.wave_tot[0] = (uint32_t)d;
+        }
+        __syncthreads();
+        uint32_t *mine = node_cnt + (size_t)lds.wave_tot[0] * 1024;
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads) mine[i] = 0;
+        if (helpers) {  // the helpers of THIS launch read the descriptor and add to the counters: publish (G16 producer form)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // a bucket that is finished by its own workgroup has decided too
+    __device__ __forceinline__ void arrive() const
+    {
+        if (helpers && threadIdx.x == 0)
+            __hip_atomic_fetch_add(&count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 };
 
-template <typename Edges>
+template <typename Edges, typename Dense>
 __device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int node_shift,
-                                              int64_t N, int32_t *__restrict__ col, const RowOutputs &o, const DenseArgs &dense)
+                                              int64_t N, int32_t *__restrict__ col, const RowOutputs &o, const Dense &dense)
 {
     uint32_t *cnt = lds.cnt, *excl = lds.excl;
     const int nb = 1 << node_shift;  // <= 1024 nodes
     const int64_t node0 = (int64_t)blockIdx.x << node_shift;
     if (seg_n > (uint32_t)kDenseMin) {  // (workgroup-uniform) split by edges over several workgroups: dense_count / dense_place
-        if (threadIdx.x == 0) {
-            const int shares = (int)((seg_n + kDensePart - 1) / kDensePart);
-            const int d = atomicAdd(&dense.count[0], 1);
-            const int first = atomicAdd(&dense.count[1], shares);
-            dense.list[d] = DenseBucket{(int32_t)blockIdx.x, first, shares, seg_n, seg_lo};
-            lds.wave_tot[0] = (uint32_t)d;
-        }
-        __syncthreads();
-        uint32_t *mine = dense.node_cnt + (size_t)lds.wave_tot[0] * 1024;
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads) mine[i] = 0;
-        if (dense.helpers) {  // the helpers of THIS launch read the descriptor and add to the counters: publish (G16 producer form)
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(&dense.count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        dense.register_bucket(lds, seg_lo, seg_n, nb);
         return;
     }
-    if (dense.helpers && threadIdx.x == 0)
-        __hip_atomic_fetch_add(&dense.count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    dense.arrive();
     for (int i = threadIdx.x; i < nb; i += kFinishThreads) cnt[i] = 0;
     __syncthreads();
-    edges.for_each([&](int2 v) { atomicAdd(&cnt[v.y - (int)node0], 1u); });
+    edges.for_each([&](int, int y) { atomicAdd(&cnt[y], 1u); });
     __syncthreads();
     scan_bucket_nodes(cnt, excl, lds.wave_tot, nb, node0, N, seg_lo, seg_n, true, o);
     __syncthreads();
@@ -723,12 +740,11 @@ __device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds
         for (int i = n_lo + threadIdx.x; i < n_hi; i += kFinishThreads) cnt[i] = excl[i] - r_lo;  // cursors relative to the range
         __syncthreads();
         if (r_n > 0) {
-            edges.for_each([&](int2 v) {
-                const int y = v.y - (int)node0;
+            edges.for_each([&](int x, int y) {
                 if (y < n_lo || y >= n_hi) return;
                 const uint32_t pos = atomicAdd(&cnt[y], 1u);
-                if (direct) col[seg_lo + r_lo + pos] = v.x;
-                else lds.image[pos] = v.x;
+                if (direct) col[seg_lo + r_lo + pos] = x;
+                else lds.image[pos] = x;
             });
             __syncthreads();
             if (!direct)
@@ -1069,7 +1085,7 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__re
     }
     const unsigned long long seg_lo = fine_base[blockIdx.x], seg_hi = fine_base[blockIdx.x + 1];
     const uint32_t seg_n = (uint32_t)(seg_hi - seg_lo);
-    finish_bucket(ContiguousEdges{staged, seg_lo, seg_n}, lds, seg_lo, seg_n, node_shift, N, col, o, dense);
+    finish_bucket(ContiguousEdges{staged, seg_lo, seg_n, (int)((int64_t)blockIdx.x << node_shift)}, lds, seg_lo, seg_n, node_shift, N, col, o, dense);
 }
 
 
@@ -1133,14 +1149,742 @@ __global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int
     }
     const uint32_t avg_run = n / (uint32_t)tiles;  // workgroup-uniform
     const int n_long = n_long_s <= kLongCap ? n_long_s : 0;  // (red_* were written behind a barrier: n_long_s is final here)
+    const int node0 = (int)((int64_t)blockIdx.x << node_shift);
     if (avg_run < 11)
-        finish_bucket(GatheredEdges<16>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, col, o, dense);
+        finish_bucket(GatheredEdges<16>{staged, seg, tiles, long_tiles, n_long, node0}, lds, base, n, node_shift, N, col, o, dense);
     else if (avg_run < 22)
-        finish_bucket(GatheredEdges<32>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, col, o, dense);
+        finish_bucket(GatheredEdges<32>{staged, seg, tiles, long_tiles, n_long, node0}, lds, base, n, node_shift, N, col, o, dense);
     else
-        finish_bucket(GatheredEdges<64>{staged, seg, tiles, long_tiles, n_long}, lds, base, n, node_shift, N, col, o, dense);
+        finish_bucket(GatheredEdges<64>{staged, seg, tiles, long_tiles, n_long, node0}, lds, base, n, node_shift, N, col, o, dense);
 }
 
+// ==== level plans: every graph the two-launch gather plan above does not take ==================================================
+// The gather plan generalised to 1 - 3 tile-sort LEVELS (round 4; replaces the count -> scan -> scatter partition passes: two
+// counting kernels that re-read the edges and three scans per pass, 3.6x the algorithmic traffic on ogbl-ppa / -citation2 size
+// graphs).  A level never needs global offsets: every 4096-edge tile is sorted by that level's key in LDS and written back
+// as one contiguous tile, together with the tile's exclusive key offsets off[key][tile] ("run descriptors").  The next level's
+// input for group G = (parent group g, key k) is the VIRTUAL concatenation of the runs (tile, k) over the tiles of g, read through
+// those descriptors and cut into 4096-edge chunks: chunk c of G becomes tile (G, c) of the next level.  What is needed between two
+// levels is small: per (g, k) a prefix of the run lengths over the tiles (level_scan_kernel: where does chunk c begin), the tile
+// ranges tb[G] of the groups (level_tiles_kernel) and the group of each tile (level_fill_kernel) -- descriptor-sized arrays, no
+// pass over the edges.  The finish launch gathers a fine bucket's runs from the tiles of its parent group exactly like
+// finish_gather_kernel; the start of the bucket in col is base[g] + sum over those tiles of off[k][tile].
+//   level 0   tile_sort_kernel          edges (16 B) -> tiles of (src, dst) int2, off0
+//   level l   regroup_sort_kernel       runs of level l - 1 -> tiles keyed by the next bits of dst; the LAST level writes packed
+//                                       4-byte records src | (dst & (2^node_shift - 1)) << src_bits when the ids fit
+//   finish    finish_runs_kernel        one workgroup per fine bucket; dense buckets are split over TILE ranges of about
+//                                       kDensePart edges each (runs are at most a tile long, so tile granularity balances them)
+// Traffic per edge: 16 + 8 (level 0) + 8 + 4 (level 1, packed) + 4 (+ 4 re-read, mostly from L2) + 4 (finish) = 44 - 48 B against
+// 72 B measured for the partition passes.
+constexpr int kMaxLevels = 3;
+constexpr int kRegroupThreads = 512;
+constexpr int kRunCap = 1024;        // run descriptors the finish step of a level plan keeps in LDS (two workgroups per CU: 80 KB each)
+constexpr int kRegroupRuns = 512;    // run descriptors a regroup workgroup holds at a time (more: further rounds)
+
+struct LevelPlan {
+    int levels;
+    int node_shift;
+    int shift[kMaxLevels];          // level l keys on dst >> shift[l]; shift[levels - 1] == node_shift
+    int keys[kMaxLevels];           // fan-out (level 0: ceil(N / 2^shift[0]) <= 256; below: powers of two <= 256)
+    int log2_keys[kMaxLevels];      // -1 at level 0
+    int64_t groups[kMaxLevels + 1]; // groups[l]: groups at the INPUT of level l (groups[0] = 1); groups[levels]: fine buckets
+    int64_t tmax[kMaxLevels];       // tile slots of level l (row stride of its descriptor arrays)
+    bool packed;                    // records of the last level are 4 bytes
+    int src_bits;                   // 32 - node_shift
+};
+
+inline int ceil_log2_i64(int64_t x)
+{
+    int b = 0;
+    while (((int64_t)1 << b) < x) ++b;
+    return b;
+}
+
+// node_shift / fine_buckets as make_plan chose them; max_src: sources are < max_src (N for edge lists, B for link lists)
+inline bool make_level_plan(int64_t N, int64_t E, int64_t max_src, int node_shift, LevelPlan &p)
+{
+    const int64_t n = N > 0 ? N : 1;
+    const int64_t fine = (n + ((int64_t)1 << node_shift) - 1) >> node_shift;
+    if (E >= ((int64_t)1 << 32) - 2 * kTile) return false;  // record indices are 32-bit
+    const int tb = ceil_log2_i64(fine);
+    if (tb > 24) return false;
+    p.node_shift = node_shift;
+    p.levels = fine <= kMaxKeys ? 1 : (tb <= 16 ? 2 : 3);
+    int below[kMaxLevels] = {0, 0, 0};  // key bits of the levels under level 0
+    if (p.levels == 2) below[1] = tb / 2;
+    if (p.levels == 3) { below[2] = tb / 3; below[1] = (tb - below[2]) / 2; }
+    int s = node_shift;
+    for (int l = p.levels - 1; l >= 1; --l) {
+        p.shift[l] = s;
+        p.keys[l] = 1 << below[l];
+        p.log2_keys[l] = below[l];
+        s += below[l];
+    }
+    p.shift[0] = s;
+    p.keys[0] = (int)((n + ((int64_t)1 << s) - 1) >> s);
+    p.log2_keys[0] = -1;
+    if (p.keys[0] > kMaxKeys) return false;
+    const int64_t tiles0 = (E + kTile - 1) / kTile;
+    p.groups[0] = 1;
+    p.tmax[0] = tiles0 > 0 ? tiles0 : 1;
+    for (int l = 1; l <= p.levels; ++l) {
+        p.groups[l] = (n + ((int64_t)1 << p.shift[l - 1]) - 1) >> p.shift[l - 1];
+        if (l < p.levels) p.tmax[l] = tiles0 + p.groups[l];
+    }
+    p.src_bits = 32 - node_shift;
+    p.packed = max_src <= ((int64_t)1 << p.src_bits) && !getenv("SS_CSR_NO_PACK");
+    return true;
+}
+
+// what a regroup workgroup needs to know about its tile, in one 32-byte load (level_fill_kernel)
+struct __attribute__((aligned(32))) TileHeader {
+    uint32_t group;       // G
+    uint32_t count;       // edges of the tile (4096 but for the last chunk of a group)
+    uint32_t start;       // first record of the tile in the level's (compact) record array
+    uint32_t position;    // 4096 * chunk: position of the tile's first edge in the concatenated runs of G
+    uint32_t first_tile;  // parent tile whose run holds that position
+    uint32_t tile_end;    // end of the parent group's tiles
+    uint32_t pad[2];
+};
+
+// descriptor arrays of one level (device)
+struct LevelArrays {
+    uint32_t *off;                 // [keys + 1][tmax]
+    uint32_t *prefix;              // [keys][tmax]     (levels that feed a regroup level)
+    uint32_t *cfirst;              // [keys][tmax]     (same levels) first tile of every chunk of every child group
+    uint32_t *tstart;              // [tmax]           (levels >= 1)
+    uint32_t *tb;                  // [groups + 1]     (levels >= 1)
+    TileHeader *header;            // [tmax]           (levels >= 1)
+    uint32_t *gcount;              // [groups]         (levels >= 1)
+    uint32_t *n_tiles;             // [1]              (levels >= 1)
+    unsigned long long *base;      // [groups]         (levels >= 1)
+};
+
+// the tiles a regroup / finish workgroup gathers its runs from
+struct ParentLevel {
+    const uint32_t *off;                // [keys + 1][tmax] exclusive key offsets inside each tile (row `keys`: the tile's edge count)
+    const uint32_t *tstart;             // [tmax] first record of each tile; nullptr: tile j starts at j * kTile (level 0)
+    const uint32_t *tb;                 // [groups + 1] tiles of each group of this level; nullptr: one group, tiles [0, tiles0)
+    const unsigned long long *base;     // [groups] first record (= first col slot) of each group; nullptr: 0
+    int tmax, tiles0, keys, log2_keys;  // log2_keys < 0: level 0, the key IS the child group
+};
+
+struct ChildGroup {
+    int g, k, t_lo, t_hi;
+    unsigned long long base;
+};
+
+__device__ __forceinline__ ChildGroup child_group(const ParentLevel &p, int64_t G)
+{
+    ChildGroup c;
+    c.g = p.log2_keys < 0 ? 0 : (int)(G >> p.log2_keys);
+    c.k = p.log2_keys < 0 ? (int)G : (int)(G & (p.keys - 1));
+    c.t_lo = p.tb ? (int)p.tb[c.g] : 0;
+    c.t_hi = p.tb ? (int)p.tb[c.g + 1] : p.tiles0;
+    c.base = p.base ? p.base[c.g] : 0ULL;
+    return c;
+}
+
+// one workgroup per group G of the NEXT level: exclusive prefix of its run lengths over the parent's tiles (prefix[k][tile]), its
+// edge count and where it starts (base of the parent group + sum over the tiles of off[k][tile], as in finish_gather_kernel)
+__global__ __launch_bounds__(1024) void level_scan_kernel(ParentLevel par, uint32_t *__restrict__ prefix, uint32_t *__restrict__ cfirst,
+                                                          uint32_t *__restrict__ gcount, unsigned long long *__restrict__ base_next,
+                                                          const int32_t *__restrict__ skip)
+{
+    __shared__ uint32_t wave_tot[1024 / kWave];
+    __shared__ unsigned long long red[1024 / kWave];
+    SS_CSR_SKIP(skip);
+    const ChildGroup c = child_group(par, blockIdx.x);
+    const uint32_t *row0 = par.off + (int64_t)c.k * par.tmax, *row1 = row0 + par.tmax;
+    uint32_t *P = prefix + (int64_t)c.k * par.tmax;
+    // chunk q of this group (positions [4096 q, 4096 q + 4096) of its concatenated runs) begins inside exactly one non-empty run: its
+    // tile goes to C[t_lo + q] (a group of T tiles has at most T chunks) -- the regroup workgroup of that chunk starts reading there
+    uint32_t *C = cfirst + (int64_t)c.k * par.tmax + c.t_lo;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    uint32_t carry = 0;
+    unsigned long long bsum = 0;
+    for (int t0 = c.t_lo; t0 < c.t_hi; t0 += 4 * 1024) {  // four consecutive tiles per thread
+        const int t = t0 + 4 * (int)threadIdx.x;
+        uint32_t len[4], run = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            len[i] = 0;
+            if (t + i < c.t_hi) {
+                const uint32_t o0 = row0[t + i];
+                len[i] = row1[t + i] - o0;
+                bsum += o0;
+            }
+            run += len[i];
+        }
+        uint32_t inc = run;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t x = __shfl_up(inc, off);
+            if (lane >= off) inc += x;
+        }
+        if (lane == kWave - 1) wave_tot[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for (int w = 0; w < 1024 / kWave; ++w) {
+            if (w < wv) pre += wave_tot[w];
+            tot += wave_tot[w];
+        }
+        uint32_t ex = carry + pre + inc - run;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t + i < c.t_hi) {
+                P[t + i] = ex;
+                const uint32_t q = (ex + kTile - 1) / kTile;
+                if (len[i] && q * kTile < ex + len[i]) C[q] = (uint32_t)(t + i);
+                ex += len[i];
+            }
+        carry += tot;
+        __syncthreads();
+    }
+    for (int off = kWave / 2; off > 0; off >>= 1) bsum += __shfl_xor(bsum, off);
+    if (lane == 0) red[wv] = bsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 1024 / kWave; ++w) bsum += red[w];
+        gcount[blockIdx.x] = carry;
+        base_next[blockIdx.x] = c.base + bsum;
+    }
+}
+
+// single workgroup: tile ranges of the groups, tb[G] = sum over the groups before G of ceil(count / 4096)
+__global__ __launch_bounds__(1024) void level_tiles_kernel(const uint32_t *__restrict__ gcount, int64_t groups, uint32_t *__restrict__ tb,
+                                                           uint32_t *__restrict__ n_tiles, const int32_t *__restrict__ skip)
+{
+    __shared__ uint32_t wave_tot[1024 / kWave];
+    SS_CSR_SKIP(skip);
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    uint32_t carry = 0;
+    for (int64_t g0 = 0; g0 < groups; g0 += 1024) {
+        const int64_t G = g0 + threadIdx.x;
+        const uint32_t x = G < groups ? (uint32_t)(((unsigned long long)gcount[G] + kTile - 1) / kTile) : 0u;
+        uint32_t inc = x;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == kWave - 1) wave_tot[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for (int w = 0; w < 1024 / kWave; ++w) {
+            if (w < wv) pre += wave_tot[w];
+            tot += wave_tot[w];
+        }
+        if (G < groups) tb[G] = carry + pre + inc - x;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tb[groups] = carry;
+        *n_tiles = carry;
+    }
+}
+
+// one wavefront per group: the headers of its tiles
+__global__ __launch_bounds__(kWave) void level_fill_kernel(ParentLevel par, const uint32_t *__restrict__ cfirst, const uint32_t *__restrict__ tb,
+                                                          const uint32_t *__restrict__ gcount, const unsigned long long *__restrict__ base,
+                                                          TileHeader *__restrict__ header, const int32_t *__restrict__ skip)
+{
+    SS_CSR_SKIP(skip);
+    const uint32_t a = tb[blockIdx.x], b = tb[blockIdx.x + 1];
+    if (a == b) return;
+    const ChildGroup c = child_group(par, blockIdx.x);
+    const uint32_t *C = cfirst + (int64_t)c.k * par.tmax + c.t_lo;
+    const uint32_t n = gcount[blockIdx.x];
+    const unsigned long long start = base[blockIdx.x];
+    for (uint32_t q = threadIdx.x; q < b - a; q += kWave) {
+        TileHeader h;
+        h.group = blockIdx.x;
+        h.position = q * (uint32_t)kTile;
+        h.count = n - h.position < (uint32_t)kTile ? n - h.position : (uint32_t)kTile;
+        h.start = (uint32_t)(start + h.position);
+        h.first_tile = C[q];
+        h.tile_end = (uint32_t)c.t_hi;
+        h.pad[0] = h.pad[1] = 0;
+        header[a + q] = h;
+    }
+}
+
+struct LevelOut {
+    void *staged;                       // int2 records, or packed uint32 records (PACKED)
+    uint32_t *off;                      // [keys + 1][tmax]
+    uint32_t *tstart;                   // [tmax]
+    const TileHeader *header;           // [tmax]
+    const uint32_t *n_tiles;
+    int tmax, keys, shift;              // key = (dst >> shift) & (keys - 1)
+    int src_bits, low_mask;             // PACKED: src | (dst & low_mask) << src_bits
+};
+
+// level >= 1: tile j = chunk c of group G; its <= 4096 edges are positions [4096 c, 4096 c + n) of the concatenated runs (tile, k)
+// of the parent group's tiles.  Thread i takes positions i, i + 512, ...: a wavefront's 64 positions share a 64-aligned block, whose
+// first run comes from a small table; the runs are <= kRegroupRuns descriptors in LDS (a chunk that spans more -- runs shorter
+// than 8 edges on average -- takes further rounds).  Then exactly tile_sort_kernel: LDS counting sort by the level's key.
+template <bool PACKED>
+__global__ __launch_bounds__(kRegroupThreads) void regroup_sort_kernel(ParentLevel par, const int2 *__restrict__ staged_in,
+                                                                       const uint32_t *__restrict__ prefix, LevelOut out,
+                                                                       const int32_t *__restrict__ skip)
+{
+    __shared__ int2 sorted[kTile];
+    __shared__ int32_t run_start[kRegroupRuns + 1];
+    __shared__ uint32_t run_addr[kRegroupRuns];
+    __shared__ uint16_t first_run[kTile / kWave];
+    __shared__ uint32_t tile_hist[kMaxKeys], tile_offs[kMaxKeys], wave_tot[kRegroupThreads / kWave];
+    SS_CSR_SKIP(skip);
+    const uint32_t j = blockIdx.x;
+    if (j >= *out.n_tiles) return;
+    const TileHeader hd = out.header[j];
+    const uint32_t G = hd.group, lo = hd.position;
+    const int cnt = (int)hd.count;
+    const int k = par.log2_keys < 0 ? (int)G : (int)(G & (par.keys - 1));
+    const int t_hi = (int)hd.tile_end;
+    const uint32_t *P = prefix + (int64_t)k * par.tmax, *row0 = par.off + (int64_t)k * par.tmax;
+    if (threadIdx.x < kMaxKeys) tile_hist[threadIdx.x] = 0;
+    constexpr int PER = kTile / kRegroupThreads;  // 8 positions per thread
+    int2 ed[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) ed[k] = make_int2(0, 0);
+    int t_base = (int)hd.first_tile, round_lo = 0;
+    for (;;) {
+        const int R = t_hi - t_base < kRegroupRuns ? t_hi - t_base : kRegroupRuns;
+        if ((int)threadIdx.x < R) {
+            const int t = t_base + threadIdx.x;
+            run_start[threadIdx.x] = (int32_t)(P[t] - lo);  // (negative for the run the chunk begins inside of)
+            run_addr[threadIdx.x] = (par.tstart ? par.tstart[t] : (uint32_t)t * (uint32_t)kTile) + row0[t];
+        }
+        if (threadIdx.x == 0) run_start[R] = t_base + R < t_hi ? (int32_t)(P[t_base + R] - lo) : 0x7FFFFFFF;
+        __syncthreads();
+        const int round_hi = run_start[R] < cnt ? run_start[R] : cnt;  // positions [round_lo, round_hi) lie in these runs
+        if (threadIdx.x < kTile / kWave) {  // first run of every 64-position block: the last run that begins at or before it
+            int p0 = (int)threadIdx.x * kWave;
+            p0 = p0 < round_lo ? round_lo : p0;
+            int a = 0, b = R;
+            while (b - a > 1) {
+                const int mid = (a + b) >> 1;
+                if (run_start[mid] <= p0) a = mid; else b = mid;
+            }
+            first_run[threadIdx.x] = (uint16_t)a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int p = (int)threadIdx.x + k * kRegroupThreads;
+            if (p >= round_lo && p < round_hi) {
+                int r = first_run[p / kWave];
+                while (run_start[r + 1] <= p) ++r;
+                ed[k] = staged_in[run_addr[r] + (uint32_t)(p - run_start[r])];
+            }
+        }
+        if (round_hi >= cnt) break;  // (workgroup-uniform)
+        round_lo = round_hi;
+        t_base += R;
+        __syncthreads();
+    }
+    // ---- LDS counting sort by this level's key (as tile_sort_kernel) ----
+    int key[PER];
+    uint32_t rank[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int p = (int)threadIdx.x + k * kRegroupThreads;
+        key[k] = p < cnt ? (ed[k].y >> out.shift) & (out.keys - 1) : -1;
+        rank[k] = key[k] >= 0 ? atomicAdd(&tile_hist[key[k]], 1u) : 0u;
+    }
+    __syncthreads();
+    const uint32_t ex = block_exclusive_scan_keys<kRegroupThreads>(threadIdx.x < kMaxKeys ? tile_hist[threadIdx.x] : 0u, wave_tot, nullptr);
+    if (threadIdx.x < kMaxKeys) tile_offs[threadIdx.x] = ex;
+    __syncthreads();
+    uint32_t *sorted32 = reinterpret_cast<uint32_t *>(sorted);
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (key[k] >= 0) {
+            const uint32_t pos = tile_offs[key[k]] + rank[k];
+            if (PACKED) sorted32[pos] = (uint32_t)ed[k].x | ((uint32_t)(ed[k].y & out.low_mask) << out.src_bits);
+            else sorted[pos] = ed[k];
+        }
+    if ((int)threadIdx.x < out.keys) out.off[(int64_t)threadIdx.x * out.tmax + j] = ex;
+    const uint32_t ts = hd.start;
+    if (threadIdx.x == 0) {
+        out.off[(int64_t)out.keys * out.tmax + j] = (uint32_t)cnt;
+        out.tstart[j] = ts;
+    }
+    __syncthreads();
+    if (PACKED) {
+        uint32_t *dst32 = reinterpret_cast<uint32_t *>(out.staged) + ts;
+        for (int q = threadIdx.x; q < cnt; q += kRegroupThreads) dst32[q] = sorted32[q];
+    } else {
+        int2 *dst2 = reinterpret_cast<int2 *>(out.staged) + ts;
+        for (int q = threadIdx.x; q < cnt; q += kRegroupThreads) dst2[q] = sorted[q];
+    }
+}
+
+// ---- finish over runs ------------------------------------------------------------------------------------------------------------
+constexpr int kRunBlocks = (kDenseMin + kTile) / kWave;  // 64-position blocks of the largest bucket a workgroup walks itself
+struct RunLds {
+    uint32_t addr[kRunCap];            // first record of the run of each listed tile
+    uint16_t start[kRunCap + 2];       // exclusive prefix of the run lengths: position of each run's first edge; [n] = total
+    uint16_t first_run[kRunBlocks + 2];  // the run that holds the first position of each 64-position block
+    uint32_t wave_tot[kFinishThreads / kWave];
+};
+static_assert(kDenseMin + kTile < 65536 && kDensePart + kTile < kDenseMin, "16-bit positions");
+
+// The runs (tile, k) of the tiles [t_lo, t_hi) as an edge source for finish_bucket / the dense steps, walked by POSITION: the edges
+// of the listed runs are numbered 0 .. total in tile order and thread i takes positions i, i + 1024, ...: every lane has an edge
+// whatever the run lengths are (16 lanes per 18-edge run left a quarter of them idle and a second dependent load for every run
+// above the lane group: 271 us for the ppa-size finish), a wavefront's 64 positions are consecutive records of one or two runs, and
+// all of a thread's loads are independent (eight in flight).  The run of a position: table lookup per 64-position block + a short
+// linear advance.  Up to kRunCap descriptors are resident in LDS; a longer range (a bucket under a heavily skewed parent group) is
+// walked batch by batch, reloading the descriptors in every for_each.  All threads call prepare / for_each (they contain barriers).
+template <bool PACKED>
+struct RunEdges {
+    const void *staged;
+    const uint32_t *row0, *row1, *tstart;  // descriptor rows k and k + 1 (indexed by tile), tile starts (nullptr: t * kTile)
+    int t_lo, t_hi;
+    RunLds *lds;
+    int src_bits, node0;
+
+    __device__ __forceinline__ bool resident() const { return t_hi - t_lo <= kRunCap; }
+
+    // descriptors of the tiles [b0, b0 + n), n <= kRunCap = kFinishThreads -> LDS; returns the number of edges in them
+    // (o0_sum: the thread's run offset inside its tile is added -- summed over the tiles of a group that is the bucket's start)
+    __device__ __forceinline__ uint32_t prepare(int b0, int n, unsigned long long *o0_sum = nullptr) const
+    {
+        const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+        uint32_t len = 0;
+        if ((int)threadIdx.x < n) {
+            const int t = b0 + threadIdx.x;
+            const uint32_t o0 = row0[t];
+            len = row1[t] - o0;
+            if (o0_sum) *o0_sum += o0;
+            lds->addr[threadIdx.x] = (tstart ? tstart[t] : (uint32_t)t * (uint32_t)kTile) + o0;
+        }
+        uint32_t inc = len;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t x = __shfl_up(inc, off);
+            if (lane >= off) inc += x;
+        }
+        if (lane == kWave - 1) lds->wave_tot[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0, total = 0;
+        for (int w = 0; w < kFinishThreads / kWave; ++w) {
+            if (w < wv) pre += lds->wave_tot[w];
+            total += lds->wave_tot[w];
+        }
+        if ((int)threadIdx.x < n) lds->start[threadIdx.x] = (uint16_t)(pre + inc - len);
+        if (threadIdx.x == 0) lds->start[n] = (uint16_t)total;
+        __syncthreads();
+        // (a bucket above kDenseMin edges is not walked by its workgroup -- it goes to the dense steps, whose shares are walkable:
+        // no table for it, its 16-bit starts are not used)
+        const uint32_t walkable = total <= (uint32_t)(kRunBlocks * kWave) ? total : 0u;
+        for (uint32_t q = threadIdx.x; q * kWave < walkable; q += kFinishThreads) {  // last run that begins at or before position 64 q
+            const uint32_t p0 = q * kWave;
+            int a = 0, b = n;
+            while (b - a > 1) {
+                const int mid = (a + b) >> 1;
+                if (lds->start[mid] <= p0) a = mid; else b = mid;
+            }
+            lds->first_run[q] = (uint16_t)a;
+        }
+        __syncthreads();
+        return total;
+    }
+    template <typename F>
+    __device__ __forceinline__ void walk(uint32_t total, F &&f) const
+    {
+        constexpr int U = PACKED ? 12 : 6;  // loads in flight per thread (a 12 K-edge bucket in one round)
+        for (uint32_t p0 = 0; p0 < total; p0 += U * kFinishThreads) {
+            uint32_t v32[U];
+            int2 v64[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t p = p0 + u * kFinishThreads + threadIdx.x;
+                if (p < total) {
+                    int r = lds->first_run[p / kWave];
+                    while (lds->start[r + 1] <= p) ++r;
+                    const uint32_t a = lds->addr[r] + (p - lds->start[r]);
+                    if (PACKED) v32[u] = reinterpret_cast<const uint32_t *>(staged)[a];
+                    else v64[u] = reinterpret_cast<const int2 *>(staged)[a];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t p = p0 + u * kFinishThreads + threadIdx.x;
+                if (p < total) {
+                    if (PACKED) f((int)(v32[u] & ((1u << src_bits) - 1u)), (int)(v32[u] >> src_bits));
+                    else f(v64[u].x, v64[u].y - node0);
+                }
+            }
+        }
+    }
+    template <typename F>
+    __device__ __forceinline__ void for_each(F &&f) const
+    {
+        if (resident()) {  // prepared by the caller
+            walk(lds->start[t_hi - t_lo], f);
+            return;
+        }
+        for (int b0 = t_lo; b0 < t_hi; b0 += kRunCap) {
+            const int n = t_hi - b0 < kRunCap ? t_hi - b0 : kRunCap;
+            __syncthreads();  // the walk of the batch before is done with the descriptors
+            const uint32_t total = prepare(b0, n);
+            walk(total, f);
+        }
+    }
+};
+
+// dense buckets of a level plan: shares are TILE ranges
+struct DenseRunBucket {
+    int32_t bucket, first_share, shares, t_hi;  // tiles of share s: [share_lo[first_share + s], s + 1 < shares ? share_lo[first_share + s + 1] : t_hi)
+    uint32_t n;
+    unsigned long long base;
+};
+
+struct DenseRunArgs {
+    int32_t *count;           // [0] dense buckets, [1] shares
+    DenseRunBucket *list;
+    uint32_t *node_cnt;       // [dense bucket][1024]
+    uint32_t *share_off;      // [share][1024]
+    uint32_t *share_lo;       // [share] first tile of each share
+    const uint32_t *row0, *row1;  // descriptor rows of the registering bucket (set per workgroup)
+    int t_lo, t_hi;
+
+    // the bucket's runs in tile order: a share ends behind the tile in which the running edge count crosses a multiple of kDensePart
+    __device__ __forceinline__ void register_bucket(FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int nb) const
+    {
+        const int shares = (int)((seg_n + kDensePart - 1) / kDensePart);
+        if (threadIdx.x == 0) {
+            const int d = atomicAdd(&count[0], 1);
+            const int first = atomicAdd(&count[1], shares);
+            list[d] = DenseRunBucket{(int32_t)blockIdx.x, first, shares, t_hi, seg_n, seg_lo};
+            share_lo[first] = (uint32_t)t_lo;
+            lds.excl[0] = (uint32_t)d;
+            lds.excl[1] = (uint32_t)first;
+        }
+        __syncthreads();
+        const int d = (int)lds.excl[0], first = (int)lds.excl[1];
+        uint32_t *mine = node_cnt + (size_t)d * 1024;
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads) mine[i] = 0;
+        const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+        uint32_t carry = 0;
+        for (int t0 = t_lo; t0 < t_hi; t0 += kFinishThreads) {
+            const int t = t0 + threadIdx.x;
+            const uint32_t len = t < t_hi ? row1[t] - row0[t] : 0u;
+            uint32_t inc = len;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t x = __shfl_up(inc, off);
+                if (lane >= off) inc += x;
+            }
+            __syncthreads();  // (wave_tot of the round before has been read)
+            if (lane == kWave - 1) lds.wave_tot[wv] = inc;
+            __syncthreads();
+            uint32_t pre = 0, tot = 0;
+            for (int w = 0; w < kFinishThreads / kWave; ++w) {
+                if (w < wv) pre += lds.wave_tot[w];
+                tot += lds.wave_tot[w];
+            }
+            const uint32_t after = carry + pre + inc, before = after - len;
+            const uint32_t s_hi = after / (uint32_t)kDensePart, s_lo = before / (uint32_t)kDensePart;
+            if (s_hi != s_lo && s_hi < (uint32_t)shares) share_lo[first + s_hi] = (uint32_t)(t + 1);  // (a run is at most a tile: one crossing)
+            carry += tot;
+        }
+    }
+    __device__ __forceinline__ void arrive() const {}
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(8))) void finish_runs_kernel(ParentLevel par, const void *__restrict__ staged,
+                                                                     const unsigned long long *__restrict__ tile_max, int tiles0, int node_shift,
+                                                                     int src_bits, int64_t N, int32_t *__restrict__ col,
+                                                                     unsigned long long *__restrict__ n_self, RowOutputs o, DenseRunArgs dense,
+                                                                     int64_t fine_buckets)
+{
+    __shared__ FinishLds lds;
+    __shared__ RunLds runs;
+    __shared__ unsigned long long red_base[kFinishThreads / kWave], red_max[kFinishThreads / kWave];
+    __shared__ uint32_t red_n[kFinishThreads / kWave];
+    SS_CSR_SKIP(o.skip);
+    const ChildGroup c = child_group(par, blockIdx.x);
+    const uint32_t *row0 = par.off + (int64_t)c.k * par.tmax, *row1 = row0 + par.tmax;
+    const int node0 = (int)((int64_t)blockIdx.x << node_shift);
+    const RunEdges<PACKED> edges{staged, row0, row1, par.tstart, c.t_lo, c.t_hi, &runs, src_bits, node0};
+    unsigned long long base = 0, mx = 0;
+    uint32_t n = 0;
+    const bool resident = edges.resident();  // (workgroup-uniform) one descriptor per thread: loaded once, for the sums and the walks
+    if (resident) {
+        const uint32_t total = edges.prepare(c.t_lo, c.t_hi - c.t_lo, &base);
+        n = threadIdx.x == 0 ? total : 0u;
+    } else {
+        for (int t = c.t_lo + threadIdx.x; t < c.t_hi; t += kFinishThreads) {
+            const uint32_t o0 = row0[t];
+            base += o0;
+            n += row1[t] - o0;
+        }
+    }
+    if (blockIdx.x == 0)  // the first workgroup also reduces max(edge_index) + 1 (the self-loop count, hashing.py:148)
+        for (int t = threadIdx.x; t < tiles0; t += kFinishThreads) {
+            const unsigned long long v = tile_max[t];
+            mx = v > mx ? v : mx;
+        }
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        base += __shfl_xor(base, off);
+        n += __shfl_xor(n, off);
+        const unsigned long long x = __shfl_xor(mx, off);
+        mx = x > mx ? x : mx;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        red_base[threadIdx.x / kWave] = base;
+        red_n[threadIdx.x / kWave] = n;
+        red_max[threadIdx.x / kWave] = mx;
+    }
+    __syncthreads();
+    base = c.base, n = 0, mx = 0;
+    for (int w = 0; w < kFinishThreads / kWave; ++w) {
+        base += red_base[w];
+        n += red_n[w];
+        mx = red_max[w] > mx ? red_max[w] : mx;
+    }
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) *n_self = mx;
+        if ((int64_t)blockIdx.x == fine_buckets - 1) o.rowptr[N] = (int64_t)(base + n);  // the last bucket ends the edge list
+    }
+    dense.row0 = row0;
+    dense.row1 = row1;
+    dense.t_lo = c.t_lo;
+    dense.t_hi = c.t_hi;
+    finish_bucket(edges, lds, base, n, node_shift, N, col, o, dense);
+}
+
+// the two dense steps of a level plan (launches of their own: they exit at once when nothing was registered)
+struct DenseRunLds {
+    uint32_t cnt[1024], excl[1024 + 1];
+    uint32_t wave_tot[kFinishThreads / kWave];
+    RunLds runs;
+    int desc;
+};
+
+// (all threads; barriers) the bucket of share `item` and its tile range; the descriptors of the range (or of its first batch) -> LDS
+template <bool PACKED>
+__device__ __forceinline__ RunEdges<PACKED> locate_run_share(DenseRunLds &lds, int item, int n_dense, const DenseRunBucket *__restrict__ list,
+                                                                 const uint32_t *__restrict__ share_lo, const ParentLevel &par,
+                                                                 const void *__restrict__ staged, int node_shift, int src_bits, DenseRunBucket &b)
+{
+    __syncthreads();  // the previous share's readers of lds are done
+    for (int i = threadIdx.x; i < n_dense; i += kFinishThreads) {
+        const int first = list[i].first_share;
+        if (item >= first && item < first + list[i].shares) lds.desc = i;
+    }
+    __syncthreads();
+    b = list[lds.desc];
+    const int s = item - b.first_share;
+    const int t_lo = (int)share_lo[item], t_hi = s + 1 < b.shares ? (int)share_lo[item + 1] : b.t_hi;
+    const ChildGroup c = child_group(par, b.bucket);
+    const uint32_t *row0 = par.off + (int64_t)c.k * par.tmax, *row1 = row0 + par.tmax;
+    RunEdges<PACKED> e{staged, row0, row1, par.tstart, t_lo, t_hi, &lds.runs, src_bits, (int)((int64_t)b.bucket << node_shift)};
+    if (e.resident()) e.prepare(t_lo, t_hi - t_lo);
+    return e;
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(kFinishThreads) void dense_count_runs_kernel(ParentLevel par, const void *__restrict__ staged, int node_shift,
+                                                                          int src_bits, const int32_t *__restrict__ dense_count,
+                                                                          const DenseRunBucket *__restrict__ list,
+                                                                          const uint32_t *__restrict__ share_lo, uint32_t *__restrict__ node_cnt,
+                                                                          uint32_t *__restrict__ share_off, const int32_t *__restrict__ skip)
+{
+    __shared__ DenseRunLds lds;
+    SS_CSR_SKIP(skip);
+    const int n_dense = dense_count[0], n_shares = dense_count[1], nb = 1 << node_shift;
+    for (int item = blockIdx.x; item < n_shares; item += gridDim.x) {
+        DenseRunBucket b;
+        const RunEdges<PACKED> edges = locate_run_share<PACKED>(lds, item, n_dense, list, share_lo, par, staged, node_shift, src_bits, b);
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = 0;
+        __syncthreads();
+        edges.for_each([&](int, int y) { atomicAdd(&lds.cnt[y], 1u); });
+        __syncthreads();
+        uint32_t *total = node_cnt + (size_t)lds.desc * 1024;
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads) {
+            const uint32_t c = lds.cnt[i];
+            share_off[(size_t)item * 1024 + i] = c ? atomicAdd(&total[i], c) : 0u;
+        }
+    }
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(kFinishThreads) void dense_place_runs_kernel(ParentLevel par, const void *__restrict__ staged, int node_shift,
+                                                                          int src_bits, int64_t N, const int32_t *__restrict__ dense_count,
+                                                                          const DenseRunBucket *__restrict__ list,
+                                                                          const uint32_t *__restrict__ share_lo,
+                                                                          const uint32_t *__restrict__ node_cnt,
+                                                                          const uint32_t *__restrict__ share_off, int32_t *__restrict__ col,
+                                                                          RowOutputs o)
+{
+    __shared__ DenseRunLds lds;
+    SS_CSR_SKIP(o.skip);
+    const int n_dense = dense_count[0], n_shares = dense_count[1], nb = 1 << node_shift;
+    for (int item = blockIdx.x; item < n_shares; item += gridDim.x) {
+        DenseRunBucket b;
+        const RunEdges<PACKED> edges = locate_run_share<PACKED>(lds, item, n_dense, list, share_lo, par, staged, node_shift, src_bits, b);
+        const uint32_t *total = node_cnt + (size_t)lds.desc * 1024;
+        // (the totals were formed by other workgroups' agent-scope atomics in the launch before)
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = total[i];
+        __syncthreads();
+        scan_bucket_nodes(lds.cnt, lds.excl, lds.wave_tot, nb, (int64_t)b.bucket << node_shift, N, b.base, b.n, item == b.first_share, o);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = lds.excl[i] + share_off[(size_t)item * 1024 + i];
+        __syncthreads();
+        const unsigned long long cbase = b.base;
+        edges.for_each([&](int x, int y) { col[cbase + atomicAdd(&lds.cnt[y], 1u)] = x; });
+    }
+}
+
+struct LevelWorkspace {
+    LevelArrays lv[kMaxLevels];
+    int2 *staged_a;                 // level 0 (tile j at j * kTile) and level 2
+    void *staged_b;                 // level 1
+    unsigned long long *tile_max;   // [tiles0]
+    unsigned long long *scratch;    // [1] n_self when the caller does not want it
+    int32_t *dense_count;           // [kDenseSyncInts] (only [0], [1] are used by the level plans)
+    DenseRunBucket *dense_list;
+    uint32_t *dense_node_cnt, *dense_share_off, *dense_share_lo;
+    size_t bytes;
+};
+
+inline LevelWorkspace carve_levels(const LevelPlan &p, int64_t E, void *base)
+{
+    LevelWorkspace w;
+    char *c = reinterpret_cast<char *>(base);
+    size_t off = 0;
+    auto take = [&](size_t n) { char *r = c ? c + off : nullptr; off += align256(n); return r; };
+    for (int l = 0; l < p.levels; ++l) {
+        LevelArrays &a = w.lv[l];
+        a.off = reinterpret_cast<uint32_t *>(take((size_t)(p.keys[l] + 1) * p.tmax[l] * 4));
+        a.prefix = reinterpret_cast<uint32_t *>(take(l + 1 < p.levels ? (size_t)p.keys[l] * p.tmax[l] * 4 : 0));
+        a.cfirst = reinterpret_cast<uint32_t *>(take(l + 1 < p.levels ? (size_t)p.keys[l] * p.tmax[l] * 4 : 0));
+        const bool sub = l >= 1;
+        a.tstart = reinterpret_cast<uint32_t *>(take(sub ? (size_t)p.tmax[l] * 4 : 0));
+        a.tb = reinterpret_cast<uint32_t *>(take(sub ? (size_t)(p.groups[l] + 1) * 4 : 0));
+        a.header = reinterpret_cast<TileHeader *>(take(sub ? (size_t)p.tmax[l] * sizeof(TileHeader) : 0));
+        a.gcount = reinterpret_cast<uint32_t *>(take(sub ? (size_t)p.groups[l] * 4 : 0));
+        a.n_tiles = reinterpret_cast<uint32_t *>(take(sub ? 4 : 0));
+        a.base = reinterpret_cast<unsigned long long *>(take(sub ? (size_t)p.groups[l] * 8 : 0));
+    }
+    w.staged_a = reinterpret_cast<int2 *>(take((size_t)p.tmax[0] * kTile * 8));
+    w.staged_b = take(p.levels >= 2 ? (size_t)(E > 0 ? E : 1) * 8 : 0);
+    w.tile_max = reinterpret_cast<unsigned long long *>(take((size_t)p.tmax[0] * 8));
+    w.scratch = reinterpret_cast<unsigned long long *>(take(8));
+    w.dense_count = reinterpret_cast<int32_t *>(take(4 * kDenseSyncInts));
+    w.dense_list = reinterpret_cast<DenseRunBucket *>(take((size_t)max_dense_buckets(E) * sizeof(DenseRunBucket)));
+    w.dense_node_cnt = reinterpret_cast<uint32_t *>(take((size_t)max_dense_buckets(E) * 1024 * 4));
+    w.dense_share_off = reinterpret_cast<uint32_t *>(take((size_t)max_dense_shares(E) * 1024 * 4));
+    w.dense_share_lo = reinterpret_cast<uint32_t *>(take((size_t)(max_dense_shares(E) + 1) * 4));
+    w.bytes = off;
+    return w;
+}
 
 }  // namespace ss
 
@@ -1281,11 +2025,90 @@ inline int dense_helpers(bool gather)
 
 }  // namespace ss
 
+// level plans take every shape the gather plan does not (SS_CSR_LEGACY=1: the round-3 partition passes, kept for A/B runs)
+static bool use_level_plan(const ss::CsrPlan &p, int64_t N, int64_t E, int64_t max_src, ss::LevelPlan &lp)
+{
+    static const bool legacy = getenv("SS_CSR_LEGACY") != nullptr;
+    return !p.gather && !legacy && ss::make_level_plan(N, E, max_src, p.node_shift, lp);
+}
+
 extern "C" size_t ss_csr_workspace_bytes(int64_t N, int64_t E)
 {
     ss::CsrPlan p;
     if (!ss::make_plan(N, E, p)) return 0;
-    return ss::carve(p, E, nullptr).bytes;
+    size_t bytes = ss::carve(p, E, nullptr).bytes;
+    ss::LevelPlan lp;
+    if (ss::make_level_plan(N, E, N, p.node_shift, lp)) {
+        const size_t b = ss::carve_levels(lp, E, nullptr).bytes;
+        bytes = b > bytes ? b : bytes;
+    }
+    return bytes;
+}
+
+static int csr_build_levels(const ss::LevelPlan &lp, const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int32_t *col,
+                            unsigned long long *n_self_or_null, const ss::RowOutputs &rows_out, int32_t *hub_count, int32_t *mega_count,
+                            int32_t *err_flag, void *workspace, hipStream_t stream, const int32_t *skip, int32_t *bad_record)
+{
+    using namespace ss;
+    const LevelWorkspace w = carve_levels(lp, E, workspace);
+    unsigned long long *n_self = n_self_or_null ? n_self_or_null : w.scratch;
+    const int tiles0 = (int)lp.tmax[0];
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles0), dim3(kSortThreads), 0, stream, src, dst, E, N, lp.shift[0], lp.keys[0], tiles0, w.staged_a,
+                       w.lv[0].off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip, bad_record);
+    SS_LAUNCH_CHECK();
+    ParentLevel par = {w.lv[0].off, nullptr, nullptr, nullptr, tiles0, tiles0, lp.keys[0], -1};
+    const void *in = w.staged_a;
+    const bool packed = lp.packed && lp.levels >= 2;
+    for (int l = 1; l < lp.levels; ++l) {
+        const LevelArrays &a = w.lv[l];
+        hipLaunchKernelGGL(level_scan_kernel, dim3((unsigned)lp.groups[l]), dim3(1024), 0, stream, par, w.lv[l - 1].prefix, w.lv[l - 1].cfirst,
+                           a.gcount, a.base, skip);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(level_tiles_kernel, dim3(1), dim3(1024), 0, stream, a.gcount, lp.groups[l], a.tb, a.n_tiles, skip);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(level_fill_kernel, dim3((unsigned)lp.groups[l]), dim3(kWave), 0, stream, par, w.lv[l - 1].cfirst, a.tb, a.gcount, a.base,
+                           a.header, skip);
+        SS_LAUNCH_CHECK();
+        void *out_buf = (l & 1) ? w.staged_b : (void *)w.staged_a;
+        const bool last = l == lp.levels - 1;
+        const LevelOut out = {out_buf, a.off, a.tstart, a.header, a.n_tiles, (int)lp.tmax[l], lp.keys[l], lp.shift[l], lp.src_bits,
+                              (1 << lp.node_shift) - 1};
+        if (last && packed)
+            hipLaunchKernelGGL(regroup_sort_kernel<true>, dim3((unsigned)lp.tmax[l]), dim3(kRegroupThreads), 0, stream, par,
+                               (const int2 *)in, w.lv[l - 1].prefix, out, skip);
+        else
+            hipLaunchKernelGGL(regroup_sort_kernel<false>, dim3((unsigned)lp.tmax[l]), dim3(kRegroupThreads), 0, stream, par,
+                               (const int2 *)in, w.lv[l - 1].prefix, out, skip);
+        SS_LAUNCH_CHECK();
+        par = ParentLevel{a.off, a.tstart, a.tb, a.base, (int)lp.tmax[l], tiles0, lp.keys[l], lp.log2_keys[l]};
+        in = out_buf;
+    }
+    const int64_t fine = lp.groups[lp.levels];
+    const DenseRunArgs dense = {w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, w.dense_share_lo, nullptr, nullptr, 0, 0};
+    const int64_t share_cap = max_dense_shares(E);
+    const unsigned dense_grid = (unsigned)(share_cap < kDenseGrid ? share_cap : kDenseGrid);
+    if (packed) {
+        hipLaunchKernelGGL(finish_runs_kernel<true>, dim3((unsigned)fine), dim3(kFinishThreads), 0, stream, par, in, w.tile_max, tiles0,
+                           lp.node_shift, lp.src_bits, N, col, n_self, rows_out, dense, fine);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(dense_count_runs_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, par, in, lp.node_shift, lp.src_bits,
+                           w.dense_count, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, skip);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(dense_place_runs_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, par, in, lp.node_shift, lp.src_bits, N,
+                           w.dense_count, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, col, rows_out);
+        SS_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(finish_runs_kernel<false>, dim3((unsigned)fine), dim3(kFinishThreads), 0, stream, par, in, w.tile_max, tiles0,
+                           lp.node_shift, lp.src_bits, N, col, n_self, rows_out, dense, fine);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(dense_count_runs_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, par, in, lp.node_shift, lp.src_bits,
+                           w.dense_count, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, skip);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(dense_place_runs_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, par, in, lp.node_shift, lp.src_bits, N,
+                           w.dense_count, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, col, rows_out);
+        SS_LAUNCH_CHECK();
+    }
+    return SS_OK;
 }
 
 static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
@@ -1361,10 +2184,14 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
         if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
         return SS_OK;
     }
-    const Workspace w = carve(p, E, workspace);
     ProfileSpan span(stream, SS_PROF_CSR);  // all launches of this build
-    unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
     const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count, skip};
+    LevelPlan lp;
+    if (use_level_plan(p, N, E, src ? N : E, lp))
+        return csr_build_levels(lp, src, dst, E, N, col, reinterpret_cast<unsigned long long *>(n_self_loops_out), rows_out, hub_count,
+                                mega_count, err_flag, workspace, stream, skip, bad_record);
+    const Workspace w = carve(p, E, workspace);
+    unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
     // the dense steps loop over the registered shares: no more workgroups than shares can exist
     const int64_t share_cap = max_dense_shares(E);
     const unsigned dense_grid = (unsigned)(share_cap < kDenseGrid ? share_cap : kDenseGrid);
