@@ -12,15 +12,15 @@
 //
 // A "fine bucket" is 2^node_shift consecutive destination nodes (<= 1024, fewer for dense graphs so that a bucket's
 // edges fit the LDS staging buffer of the last step).
-//   pass 1  count_keys -> scan_block_counts -> scan_bases -> scatter_tiles    edges -> <= 256 buckets by dst >> shift1
-//   pass 2  (only when there are more than 256 fine buckets) the same three steps inside every pass-1 bucket,
-//           a fixed number of workgroups per bucket, <= 256 sub-buckets each
-//   pass 3  (only when there are more than 65 536 fine buckets: N > 67 M nodes, or > 4 M nodes of a dense graph) once more
-//           inside every pass-2 bucket
-//   finish  one workgroup per fine bucket: LDS histogram over its nodes, LDS scan -> rowptr, sources placed into an
-//           LDS image of the bucket's col segment and streamed out (oversized buckets: several node sub-ranges)
-// The pass-1 scatter also validates ids and reduces max(id)+1 (the self-loop count of add_self_loops,
+//   gather plan  (<= 256 fine buckets, <= 1536 tiles: every shape up to ogbl-collab size) tile_sort -> finish_gather, two launches
+//   level plans  (everything else) 1 - 3 tile-sort levels read through run descriptors -> finish_runs (see "level plans" below)
+//   finish       one workgroup per fine bucket: LDS histogram over its nodes, LDS scan -> rowptr, sources placed into an
+//                LDS image of the bucket's col segment and streamed out (oversized buckets: several node sub-ranges; dense
+//                buckets: split over several workgroups)
+// No counting pass over the edges and no scan over counters anywhere: the sorted tiles are written in place and located through
+// their per-tile key offsets.  The first level also validates ids and reduces max(id)+1 (the self-loop count of add_self_loops,
 // hashing.py:148); the finish step lists hub rows.  Nothing synchronises with the host.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -28,52 +28,34 @@
 
 namespace ss {
 
-constexpr int kThreads = 256;
-#ifndef SS_COUNT_DEPTH
-#define SS_COUNT_DEPTH 4
-#endif
-constexpr int kTile = 4096;            // edges sorted in LDS at a time by the scatter step
-constexpr int kMaxKeys = 256;          // partition fan-out per pass
-constexpr int kMaxBlocks1 = 2048;      // pass-1 slices
+constexpr int kTile = 4096;            // edges sorted in LDS at a time by a tile-sort level
+constexpr int kMaxKeys = 256;          // fan-out of a tile-sort level
 constexpr int kFinishThreads = 1024;      // (512: bench graph 46-48 us, rank^-0.5 133-137, rank^-0.9 640; 1024: 45, 121, 567)
 constexpr int kFinishCap = 16384;      // edges staged in LDS by the finish step (64 KiB)
-constexpr int kMaxTiles = 1536;        // single-pass plan: tiles whose run descriptors fit the finish step's LDS beside the image (2 workgroups per CU)
+constexpr int kMaxTiles = 1536;        // gather plan: tiles whose run descriptors fit the finish step's LDS beside the image (2 workgroups per CU)
 // Dense fine buckets (node ids correlated with degree: power-law graphs put 5 - 40 % of the edges into the first 1024 nodes) are
 // NOT finished by their one workgroup -- a single CU reading the segment twice was the whole build on such graphs (532 us of a
 // 1.23 ms step at rank^-0.9 endpoints, 97 us at rank^-0.5 against 21 us uniform).  The finish launch only registers them; two
-// further launches split each by EDGES over several workgroups: dense_count (LDS histogram of a share, ONE global atomic per
+// further steps split each by EDGES over several workgroups: dense_count (LDS histogram of a share, ONE global atomic per
 // touched node and share: its return value is the share's offset inside the node's row) and dense_place (row starts from the
 // summed counters, sources stored at start + share offset + LDS cursor).  Both exit at once when nothing was registered.
 constexpr int kDenseMin = 32768;       // a fine bucket with more edges than this is split ...
 constexpr int kDensePart = 16384;      // ... into shares of about this many edges
 constexpr int kDenseGrid = 1024;       // workgroups of the two dense launches (each loops over the shares)
 // dense_count words: [0] dense buckets, [1] shares, [3] helpers done counting, [kArriveBase + 16 k] (k < kArriveWords, one cache
-// line each) fine buckets whose workgroup has decided -- 64 sharded words: a large graph has tens of thousands of fine buckets
-// and one word takes ~90 atomics per microsecond
+// line each) fine buckets whose workgroup has decided -- 64 sharded words: one word takes ~90 atomics per microsecond
 constexpr int kArriveBase = 16, kArriveWords = 64, kDenseSyncInts = kArriveBase + 16 * kArriveWords;
 
 struct CsrPlan {
     int node_shift;       // fine bucket = dst >> node_shift
     int64_t fine_buckets;
-    bool two_pass;
-    int shift1;           // pass-1 key = dst >> shift1
-    int keys1;            // number of pass-1 buckets (<= 256)
-    int keys2;            // sub-buckets per pass-1 bucket (two_pass only, <= 256)
-    int blocks1;
-    int64_t slice1;
-    int parts2;           // workgroups per pass-1 bucket in pass 2
-    bool three_pass;      // more than 65 536 fine buckets: pass 2 stops at shift2, pass 3 (256 keys) reaches node_shift
-    int shift2;           // pass-2 key = dst >> shift2 (three_pass only; otherwise pass 2 keys on node_shift)
-    int keys3, parts3;
-    int64_t groups3;      // keys1 * keys2 pass-2 buckets, each partitioned by pass 3
-    bool gather;          // single-pass plan in two launches: tile_sort_kernel + finish_gather_kernel
-    int tiles;            // 4096-edge tiles (gather plan)
+    bool gather;          // <= 256 fine buckets and <= kMaxTiles tiles: two launches, tile_sort_kernel + finish_gather_kernel
+    int tiles;            // 4096-edge tiles
 };
 
-// average edges of a fine bucket the multi-pass plans aim for.  The finish step stages kFinishCap = 16 384 edges in LDS; a bucket
+// average edges of a fine bucket the level plans aim for.  The finish step stages kFinishCap = 16 384 edges in LDS; a bucket
 // above that takes node sub-ranges, above kDenseMin it is split by edges over several workgroups -- which is why the target can sit
-// at 3/4 of the cap instead of the former 1/2: half as many finish workgroups, each with the same fixed latencies (ppa-size graph:
-// finish 247 -> 186 us, build 888 -> 813 us; citation2-size: 337 -> 247 us, 1 228 -> 1 117 us).  SS_CSR_BUCKET_EDGES: tuning hook
+// at 3/4 of the cap instead of 1/2: half as many finish workgroups, each with the same fixed latencies.  SS_CSR_BUCKET_EDGES: tuning hook
 inline int64_t bucket_edges_target()
 {
     static const int64_t env = getenv("SS_CSR_BUCKET_EDGES") ? atoll(getenv("SS_CSR_BUCKET_EDGES")) : 0;
@@ -84,82 +66,38 @@ inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
 {
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31)) return false;
     const int64_t n = N > 0 ? N : 1;
-    // fine bucket = 1024 nodes when that gives <= 256 buckets (one partition pass; the finish step copes with dense
-    // buckets through node sub-ranges); otherwise two passes and a bucket sized for about kFinishCap / 2 edges on
-    // average, between 64 and 1024 nodes
+    // fine bucket = 1024 nodes when that gives <= 256 buckets (one tile-sort level; the finish step copes with dense buckets
+    // through node sub-ranges and the dense steps); otherwise a bucket sized for about 3/4 kFinishCap edges on average, between 64
+    // and 1024 nodes, reached by two or three levels
     int shift = 10;
     if (((n + 1023) >> 10) > kMaxKeys)
         while (shift > 6 && (E / n) * ((int64_t)1 << shift) > bucket_edges_target()) --shift;
-    if (const char *forced = getenv("SS_CSR_NODE_SHIFT")) {  // test hook: reach the multi-pass plans with small graphs
+    if (const char *forced = getenv("SS_CSR_NODE_SHIFT")) {  // test hook: reach the three-level plans with small graphs
         const int f = atoi(forced);
         if (f >= 4 && f <= 10) shift = f;
     }
     p.node_shift = shift;
     p.fine_buckets = (n + ((int64_t)1 << shift) - 1) >> shift;
-    p.two_pass = p.fine_buckets > kMaxKeys;
-    p.three_pass = false;
-    p.shift2 = shift;
-    p.keys3 = 1;
-    p.parts3 = 1;
-    p.groups3 = 0;
-    if (!p.two_pass) {
-        p.shift1 = shift;
-        p.keys1 = (int)p.fine_buckets;
-        p.keys2 = 1;
-    } else {
-        int s1 = shift;
-        while (((n + ((int64_t)1 << s1) - 1) >> s1) > kMaxKeys) ++s1;
-        if (s1 - shift > 16) return false;  // would need a fourth pass (N > 2^30 nodes at 64-node buckets)
-        p.shift1 = s1;
-        p.keys1 = (int)((n + ((int64_t)1 << s1) - 1) >> s1);
-        if (s1 - shift <= 8) {
-            p.keys2 = 1 << (s1 - shift);
-        } else {  // N > 256 * 256 fine buckets (4 M nodes at 64-node buckets, 67 M at 1024): one more 8-bit partition
-            p.three_pass = true;
-            p.shift2 = shift + 8;
-            p.keys2 = 1 << (s1 - p.shift2);
-            p.keys3 = 256;
-            p.groups3 = (int64_t)p.keys1 * p.keys2;
-        }
-    }
-    int64_t b1 = (E + kTile - 1) / kTile;
-    if (b1 < 1) b1 = 1;
-    if (b1 > kMaxBlocks1) b1 = kMaxBlocks1;
-    p.blocks1 = (int)b1;
-    p.slice1 = (E + b1 - 1) / b1;
-    // workgroups of a second / third partition pass: a FIXED number per bucket of the pass before, so a skewed graph's largest
-    // bucket decides how long the pass takes -- 8 192 in all (2 048: ppa-size graph with rank^-0.5 endpoints 1 191 us per build,
-    // 8 192: 883 us; the uniform graph 889 us either way).  SS_CSR_PARTS: tuning hook
-    static const int parts_budget = getenv("SS_CSR_PARTS") ? atoi(getenv("SS_CSR_PARTS")) : 8192;
-    int parts = (parts_budget > 0 ? parts_budget : 8192) / (p.keys1 > 0 ? p.keys1 : 1);
-    if (parts < 1) parts = 1;
-    if (parts > 64) parts = 64;
-    p.parts2 = parts;
     p.tiles = (int)((E + kTile - 1) / kTile);
-    p.gather = !p.two_pass && E > 0 && (E + kTile - 1) / kTile <= kMaxTiles && !getenv("SS_CSR_NO_GATHER");
+    // SS_CSR_NO_GATHER: test hook, small graphs through the one-level plan of the level builder
+    p.gather = p.fine_buckets <= kMaxKeys && E > 0 && (E + kTile - 1) / kTile <= kMaxTiles && !getenv("SS_CSR_NO_GATHER");
     return true;
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct DenseBucket {  // a fine bucket left to the dense launches
+struct DenseBucket {  // a fine bucket left to the dense steps (gather plan)
     int32_t bucket, first_share, shares;
     uint32_t n;                 // edges
     unsigned long long base;    // start of the bucket in col
 };
 
-struct Workspace {
-    uint32_t *counts1;              // [keys1][blocks1]
-    unsigned long long *base1;      // [keys1 + 1]
-    uint32_t *counts2;              // [keys1][keys2][parts2]
-    unsigned long long *fine_base;  // [fine_buckets + 1] (three_pass: [groups3 + 1], the pass-2 bucket bases)
-    uint32_t *counts3;              // [groups3][keys3][parts3]
-    unsigned long long *fine_base3; // [fine_buckets + 1]
+struct Workspace {  // gather plan
     unsigned long long *scratch;    // [1] n_self when the caller does not want it
-    int2 *staged_a, *staged_b;      // [E] each
-    uint32_t *tile_off;             // gather plan: [keys1 + 1][tiles]
-    unsigned long long *tile_max;   // gather plan: [tiles]
-    int32_t *dense_count;           // [2] {dense buckets, shares}
+    int2 *staged_a;                 // [E]
+    uint32_t *tile_off;             // [fine_buckets + 1][tiles]
+    unsigned long long *tile_max;   // [tiles]
+    int32_t *dense_count;           // [kDenseSyncInts]
     DenseBucket *dense_list;        // [max_dense]
     uint32_t *dense_node_cnt;       // [max_dense][1024] edges per node of a dense bucket
     uint32_t *dense_share_off;      // [max_shares][1024] offset of a share's edges inside each node's row
@@ -175,17 +113,10 @@ inline Workspace carve(const CsrPlan &p, int64_t E, void *base)
     char *c = reinterpret_cast<char *>(base);
     size_t off = 0;
     auto take = [&](size_t n) { char *r = c ? c + off : nullptr; off += align256(n); return r; };
-    w.counts1 = reinterpret_cast<uint32_t *>(take((size_t)p.keys1 * p.blocks1 * 4));
-    w.base1 = reinterpret_cast<unsigned long long *>(take((size_t)(p.keys1 + 1) * 8));
-    w.counts2 = reinterpret_cast<uint32_t *>(take(p.two_pass ? (size_t)p.keys1 * p.keys2 * p.parts2 * 4 : 0));
-    w.fine_base = reinterpret_cast<unsigned long long *>(take(p.two_pass ? (size_t)((p.three_pass ? p.groups3 : p.fine_buckets) + 1) * 8 : 0));
-    w.counts3 = reinterpret_cast<uint32_t *>(take(p.three_pass ? (size_t)p.groups3 * p.keys3 * p.parts3 * 4 : 0));
-    w.fine_base3 = reinterpret_cast<unsigned long long *>(take(p.three_pass ? (size_t)(p.fine_buckets + 1) * 8 : 0));
     w.scratch = reinterpret_cast<unsigned long long *>(take(8));
     w.staged_a = reinterpret_cast<int2 *>(take((size_t)(E > 0 ? E : 1) * 8));
-    w.staged_b = reinterpret_cast<int2 *>(take(p.two_pass ? (size_t)(E > 0 ? E : 1) * 8 : 0));
-    w.tile_off = reinterpret_cast<uint32_t *>(take(p.gather ? (size_t)(p.keys1 + 1) * p.tiles * 4 : 0));
-    w.tile_max = reinterpret_cast<unsigned long long *>(take(p.gather ? (size_t)p.tiles * 8 : 0));
+    w.tile_off = reinterpret_cast<uint32_t *>(take((size_t)(p.fine_buckets + 1) * p.tiles * 4));
+    w.tile_max = reinterpret_cast<unsigned long long *>(take((size_t)p.tiles * 8));
     w.dense_count = reinterpret_cast<int32_t *>(take(4 * kDenseSyncInts));
     w.dense_list = reinterpret_cast<DenseBucket *>(take((size_t)max_dense_buckets(E) * sizeof(DenseBucket)));
     w.dense_node_cnt = reinterpret_cast<uint32_t *>(take((size_t)max_dense_buckets(E) * 1024 * 4));
@@ -194,30 +125,8 @@ inline Workspace carve(const CsrPlan &p, int64_t E, void *base)
     return w;
 }
 
-// ---- block-wide exclusive scan of 256 values, one per thread (kThreads == 256) ---------------------------------------
-__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t x, uint32_t *wave_tot /* LDS [4] */, uint32_t *total)
-{
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    uint32_t inc = x;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-    }
-    if (lane == kWave - 1) wave_tot[wv] = inc;
-    __syncthreads();
-    uint32_t pre = 0, tot = 0;
-    for (int w = 0; w < kThreads / kWave; ++w) {
-        if (w < wv) pre += wave_tot[w];
-        tot += wave_tot[w];
-    }
-    if (total) *total = tot;
-    __syncthreads();
-    return pre + inc - x;
-}
-
-// the same scan of the 256 key counters inside a workgroup of THREADS >= 256 threads: thread k < 256 owns key k, the other
-// wavefronts contribute zeros (tile sort / tile scatter run 512 threads per 4096-edge tile: 8 edges per thread)
+// ---- block-wide exclusive scan of the 256 key counters inside a workgroup of THREADS >= 256 threads: thread k < 256 owns key k, the other
+// wavefronts contribute zeros (tile sort / regroup run 512 threads per 4096-edge tile: 8 edges per thread)
 template <int THREADS>
 __device__ __forceinline__ uint32_t block_exclusive_scan_keys(uint32_t x /* 0 for threads >= 256 */, uint32_t *wave_tot /* LDS [THREADS / 64] */,
                                                               uint32_t *total)
@@ -241,314 +150,32 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_keys(uint32_t x /* 0 fo
     return pre + inc - x;
 }
 
-// Entry e of the caller's list as (source, destination).  Edge lists: src[e], dst[e].  LINK lists (ss_group_links_by_source:
-// the pairs of a query grouped by their first node): src == nullptr, dst = links [B, 2] -- the key is the pair's first node,
-// torch-style negative ids wrapped, ids out of range keyed to node 0 (the query kernel itself reports them and writes their NaN
-// rows: nothing may be dropped here), and the "source" is the pair's index.
-__device__ __forceinline__ void fetch_edge(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t e, int64_t N, int64_t &s,
-                                           int64_t &d)
-{
-    if (src) {
-        s = src[e];
-        d = dst[e];
-    } else {
-        int64_t u = dst[2 * e];
-        u = u < 0 ? u + N : u;
-        d = (uint64_t)u < (uint64_t)N ? u : 0;
-        s = e;
-    }
-}
-
-// where a workgroup's edges come from and how they are keyed
-struct PassArgs {
-    const int64_t *src, *dst;            // pass 1 input: slices of the caller's edge list (src == nullptr: a link list, see fetch_edge)
-    const int2 *staged;                  // pass 2 input: parts of one pass-1 bucket
-    const unsigned long long *seg_base;  // pass 2: base1[keys1 + 1]
-    int64_t E, N, slice;                 // pass 1
-    int shift, sub_shift, keys, parts;   // key = dst >> shift (pass 1) | (dst >> sub_shift) - (bucket << (shift - sub_shift)) (pass 2)
-    const int32_t *skip;                 // nullable: *skip != 0 -> the outputs already hold this CSR (ss_csr_build_cached), every kernel exits
-    int32_t *bad_record;                 // nullable: set beside *err when ids out of range are met (FingerprintWords.bad)
-};
-
-// first statement of every kernel of a build (workgroup-uniform: one word)
+// first statement of every kernel of a build (workgroup-uniform: one word): *skip != 0 -> the outputs already hold this CSR
+// (ss_csr_build_cached), every kernel exits
 #define SS_CSR_SKIP(word)            \
     do {                             \
         if ((word) && *(word)) return; \
     } while (0)
 
-template <bool PASS2>
-__device__ __forceinline__ void block_range(const PassArgs &a, int64_t &lo, int64_t &hi, int &group, int &part, int &parts)
-{
-    if (!PASS2) {
-        group = 0;
-        part = blockIdx.x;
-        parts = gridDim.x;
-        lo = (int64_t)blockIdx.x * a.slice;
-        hi = lo + a.slice < a.E ? lo + a.slice : a.E;
-        if (lo > a.E) lo = a.E;
-    } else {
-        group = blockIdx.x / a.parts;
-        part = blockIdx.x % a.parts;
-        parts = a.parts;
-        const int64_t s = (int64_t)a.seg_base[group], e = (int64_t)a.seg_base[group + 1];
-        // (shares rounded up to whole tiles -- a 1.27-tile share sorts a tile that is a quarter full -- measured: ppa size 820 -> 831 us,
-        // citation2 size level; the extra workgroups matter more than the short runs)
-        const int64_t per = (e - s + a.parts - 1) / a.parts;
-        lo = s + per * part;
-        if (lo > e) lo = e;
-        hi = lo + per < e ? lo + per : e;
-    }
-}
-
-template <bool PASS2>
-__device__ __forceinline__ int key_of(const PassArgs &a, int64_t d, int group)
-{
-    return PASS2 ? (int)((d >> a.sub_shift) - ((int64_t)group << (a.shift - a.sub_shift))) : (int)(d >> a.shift);
-}
-
-// counts[(group * keys + key) * parts + part]
-template <bool PASS2>
-__global__ __launch_bounds__(kThreads) void count_keys_kernel(PassArgs a, uint32_t *__restrict__ counts, int32_t *__restrict__ err,
-                                                              unsigned long long *__restrict__ n_self, int32_t *__restrict__ hub_count,
-                                                              int32_t *__restrict__ mega_count, int32_t *__restrict__ dense_count)
-{
-    __shared__ uint32_t hist[kMaxKeys];
-    SS_CSR_SKIP(a.skip);
-    if (!PASS2 && blockIdx.x == 0 && threadIdx.x == 0) {  // outputs of later kernels of this build are cleared here
-        *n_self = 0ULL;
-        if (hub_count) *hub_count = 0;
-        if (mega_count) mega_count[0] = mega_count[1] = 0;
-        dense_count[0] = dense_count[1] = dense_count[2] = dense_count[3] = 0;
-    }
-    if (!PASS2 && blockIdx.x == 0 && threadIdx.x < kArriveWords) dense_count[kArriveBase + 16 * threadIdx.x] = 0;
-    hist[threadIdx.x] = 0;
-    __syncthreads();
-    int64_t lo, hi;
-    int group, part, parts;
-    block_range<PASS2>(a, lo, hi, group, part, parts);
-    bool bad = false;
-    constexpr int kDepth = SS_COUNT_DEPTH;  // loads in flight per thread
-    for (int64_t e0 = lo; e0 < hi; e0 += kDepth * kThreads) {
-        int64_t d[kDepth];
-#pragma unroll
-        for (int k = 0; k < kDepth; ++k) {
-            const int64_t e = e0 + threadIdx.x + (int64_t)k * kThreads;
-            d[k] = -1;
-            if (e < hi) {
-                if (PASS2) {
-                    d[k] = (int64_t)a.staged[e].y;
-                } else {
-                    int64_t s_unused;
-                    fetch_edge(a.src, a.dst, e, a.N, s_unused, d[k]);
-                }
-            }
-            if (!PASS2 && e < hi && (uint64_t)d[k] >= (uint64_t)a.N) {  // out of range: dropped (and reported)
-                bad = true;
-                d[k] = -1;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kDepth; ++k)
-            if (d[k] >= 0) atomicAdd(&hist[key_of<PASS2>(a, d[k], group)], 1u);
-    }
-    if (bad && err) *err = 1;
-    if (bad && a.bad_record) *a.bad_record = 1;
-    __syncthreads();
-    if ((int)threadIdx.x < a.keys) counts[((int64_t)group * a.keys + threadIdx.x) * parts + part] = hist[threadIdx.x];
-}
-
-// pass 1: one wave per key: exclusive scan of that key's counts over the slices (in place) + key total
-__global__ __launch_bounds__(kThreads) void scan_block_counts_kernel(uint32_t *__restrict__ counts, int blocks, int keys,
-                                                                     unsigned long long *__restrict__ key_total, const int32_t *__restrict__ skip)
-{
-    SS_CSR_SKIP(skip);
-    const int lane = threadIdx.x & (kWave - 1);
-    const int k = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
-    if (k >= keys) return;
-    unsigned long long carry = 0;
-    for (int g0 = 0; g0 < blocks; g0 += kWave) {
-        const int g = g0 + lane;
-        const uint32_t x = g < blocks ? counts[(int64_t)k * blocks + g] : 0u;
-        uint32_t inc = x;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
-        }
-        // offsets inside one key stay below 2^32 (E < 2^32 per key is enforced by the int32 staging anyway)
-        if (g < blocks) counts[(int64_t)k * blocks + g] = (uint32_t)carry + inc - x;
-        carry += __shfl(inc, kWave - 1);
-    }
-    if (lane == 0) key_total[k] = carry;
-}
-
-// pass 1: single workgroup: key totals -> exclusive bases (in place), grand total appended and written to rowptr[N]
-__global__ __launch_bounds__(kThreads) void scan_bases_kernel(unsigned long long *__restrict__ key_total, int keys,
-                                                              int64_t *__restrict__ rowptr, int64_t N, const int32_t *__restrict__ skip)
-{
-    __shared__ unsigned long long vals[kMaxKeys];
-    SS_CSR_SKIP(skip);
-    vals[threadIdx.x] = (int)threadIdx.x < keys ? key_total[threadIdx.x] : 0ULL;
-    __syncthreads();
-    if (threadIdx.x == 0) {  // <= 256 values: a serial scan is a few hundred cycles
-        unsigned long long run = 0;
-        for (int k = 0; k < keys; ++k) {
-            const unsigned long long v = vals[k];
-            vals[k] = run;
-            run += v;
-        }
-        key_total[keys] = run;
-        rowptr[N] = (int64_t)run;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < keys) key_total[threadIdx.x] = vals[threadIdx.x];
-}
-
-// pass 2: one workgroup per pass-1 bucket: scan its [keys2][parts2] matrix (key-major) into offsets relative to the
-// bucket's segment start, and write the absolute bases of its fine buckets
-__global__ __launch_bounds__(kThreads) void scan_sub_counts_kernel(uint32_t *__restrict__ counts2, int keys2, int parts2,
-                                                                   const unsigned long long *__restrict__ base1,
-                                                                   unsigned long long *__restrict__ fine_base, int64_t fine_buckets,
-                                                                   int keys1, const int32_t *__restrict__ skip)
-{
-    __shared__ uint32_t wave_tot[kThreads / kWave];
-    SS_CSR_SKIP(skip);
-    const int c = blockIdx.x;
-    uint32_t *m = counts2 + (int64_t)c * keys2 * parts2;
-    uint32_t sum = 0;  // thread k owns key k: its parts2 counters are consecutive
-    if ((int)threadIdx.x < keys2)
-        for (int q = 0; q < parts2; ++q) sum += m[(int64_t)threadIdx.x * parts2 + q];
-    const uint32_t ex = block_exclusive_scan_256(sum, wave_tot, nullptr);
-    if ((int)threadIdx.x < keys2) {
-        uint32_t run = ex;
-        for (int q = 0; q < parts2; ++q) {
-            const uint32_t v = m[(int64_t)threadIdx.x * parts2 + q];
-            m[(int64_t)threadIdx.x * parts2 + q] = run;
-            run += v;
-        }
-        const int64_t f = (int64_t)c * keys2 + threadIdx.x;
-        if (f < fine_buckets) fine_base[f] = base1[c] + ex;
-    }
-    if (c == keys1 - 1 && threadIdx.x == 0) fine_base[fine_buckets] = base1[keys1];  // keys1 = number of groups of this pass
-}
-
-// tile-sorted scatter: every 4096-edge tile is ordered by key in LDS, then written as contiguous runs
-constexpr int kScatterThreads = 512;  // 8 edges per thread and tile (256 x 16: ppa-like pass 1 / pass 2 293 / 201 us)
-
-template <bool PASS2>
-__global__ __launch_bounds__(kScatterThreads) void scatter_tiles_kernel(PassArgs a, const uint32_t *__restrict__ offsets,
-                                                                 const unsigned long long *__restrict__ key_base, int2 *__restrict__ out,
-                                                                 unsigned long long *__restrict__ n_self, int32_t *__restrict__ err)
-{
-    __shared__ int2 sorted[kTile];
-    __shared__ uint32_t tile_hist[kMaxKeys], tile_off[kMaxKeys], wave_tot[kScatterThreads / kWave];
-    __shared__ unsigned long long cursor[kMaxKeys];
-    __shared__ unsigned long long block_max;
-    SS_CSR_SKIP(a.skip);
-    int64_t lo, hi;
-    int group, part, parts;
-    block_range<PASS2>(a, lo, hi, group, part, parts);
-    const bool key_owner = threadIdx.x < kMaxKeys;  // thread k < 256 owns key k
-    if (key_owner) cursor[threadIdx.x] = 0;
-    if ((int)threadIdx.x < a.keys) {
-        const uint32_t off = offsets[((int64_t)group * a.keys + threadIdx.x) * parts + part];
-        cursor[threadIdx.x] = PASS2 ? a.seg_base[group] + off : key_base[threadIdx.x] + off;
-    }
-    if (key_owner) tile_hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) block_max = 0;
-    __syncthreads();
-    constexpr int PER = kTile / kScatterThreads;  // 8 edges per thread and tile
-    int64_t my_max = -1;
-    bool bad = false;
-    for (int64_t t0 = lo; t0 < hi; t0 += kTile) {
-        int2 ed[PER];
-        int key[PER];
-        uint32_t rank[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int64_t e = t0 + threadIdx.x + (int64_t)k * kScatterThreads;
-            key[k] = -1;
-            ed[k] = make_int2(0, 0);
-            if (e < hi) {
-                int64_t s, d;
-                if (PASS2) {
-                    const int2 v = a.staged[e];
-                    s = v.x;
-                    d = v.y;
-                } else {
-                    fetch_edge(a.src, a.dst, e, a.N, s, d);
-                    const int64_t mx = s > d ? s : d;
-                    my_max = mx > my_max ? mx : my_max;
-                    if ((uint64_t)d >= (uint64_t)a.N) continue;               // dropped, exactly as count_keys did
-                    if (a.src && (uint64_t)s >= (uint64_t)a.N) { bad = true; s = 0; }  // memory safe; the host raises in strict mode
-                }
-                ed[k] = make_int2((int)s, (int)d);
-                key[k] = key_of<PASS2>(a, d, group);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < PER; ++k) rank[k] = key[k] >= 0 ? atomicAdd(&tile_hist[key[k]], 1u) : 0u;
-        __syncthreads();
-        uint32_t tile_n = 0;
-        const uint32_t ex = block_exclusive_scan_keys<kScatterThreads>(key_owner ? tile_hist[threadIdx.x] : 0u, wave_tot, &tile_n);
-        if (key_owner) tile_off[threadIdx.x] = ex;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-            if (key[k] >= 0) sorted[tile_off[key[k]] + rank[k]] = ed[k];
-        __syncthreads();
-        for (uint32_t q = threadIdx.x; q < tile_n; q += kScatterThreads) {
-            const int2 v = sorted[q];
-            const int kq = key_of<PASS2>(a, (int64_t)v.y, group);
-            out[cursor[kq] + (q - tile_off[kq])] = v;
-        }
-        __syncthreads();
-        if (key_owner) {
-            cursor[threadIdx.x] += tile_hist[threadIdx.x];
-            tile_hist[threadIdx.x] = 0;
-        }
-        __syncthreads();
-    }
-    if (!PASS2) {
-        unsigned long long m = my_max < 0 ? 0ULL : (unsigned long long)my_max + 1ULL;
-        for (int off = kWave / 2; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(m, off);
-            m = o > m ? o : m;
-        }
-        if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(&block_max, m);
-        if (bad && err) *err = 1;
-        if (bad && a.bad_record) *a.bad_record = 1;
-        __syncthreads();
-        if (threadIdx.x == 0 && block_max) atomicMax(n_self, block_max);
-    }
-}
+#ifdef SS_CSR_TIMING  // measurement build only (SS_EXTRA_FLAGS=-DSS_CSR_TIMING): where a finish workgroup's time goes
+__device__ unsigned long long csr_phase_ticks[16];
+#define SS_TICK(i)                                                                                   \
+    do {                                                                                             \
+        if (threadIdx.x == 0) {                                                                      \
+            const unsigned long long now_ = wall_clock64();                                          \
+            atomicAdd(&csr_phase_ticks[i], now_ - tick_);                                            \
+            tick_ = now_;                                                                            \
+        }                                                                                            \
+    } while (0)
+#define SS_TICK_START() unsigned long long tick_ = wall_clock64()
+#else
+#define SS_TICK(i)
+#define SS_TICK_START()
+#endif
 
 // ---- finish: one workgroup per fine bucket --------------------------------------------------------------------------------
-// The bucket's edges reach the workgroup through an "edge source" with for_each(f): either one contiguous run of the staged
-// array (partition passes: ContiguousEdges) or one short run per 4096-edge tile of the tile-sorted array (single-pass plan:
-// GatheredEdges, see tile_sort_kernel).
-struct ContiguousEdges {
-    const int2 *staged;
-    unsigned long long seg_lo;
-    uint32_t seg_n;
-    int node0;  // first node of the bucket: f(source, destination - node0)
-    template <typename F>
-    __device__ __forceinline__ void for_each(F &&f) const
-    {
-        for (uint32_t q0 = 0; q0 < seg_n; q0 += 4 * kFinishThreads) {
-            int2 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t q = q0 + threadIdx.x + k * kFinishThreads;
-                v[k] = q < seg_n ? staged[seg_lo + q] : make_int2(0, -1);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (v[k].y >= 0) f(v[k].x, v[k].y - node0);
-        }
-    }
-};
-
+// The bucket's edges reach the workgroup through an "edge source" with for_each(f): one short run per 4096-edge tile of the
+// tile-sorted array (gather plan: GatheredEdges, see tile_sort_kernel; level plans: RunEdges).
 // LANES lanes read one tile's run; chosen from the average run length of the bucket (tile / buckets = ~18 edges on the bench
 // graph -> 32 lanes; skewed buckets whose runs are hundreds of edges -> whole wavefronts), so that most runs need one load
 constexpr int kLongRun = 256;   // runs above this many edges (a SORTED stretch of the edge list -- e.g. the self loops ELPH
@@ -561,6 +188,11 @@ struct GatheredEdges {
     const uint16_t *long_tiles;  // LDS: tiles whose run is longer than kLongRun (listed by the kernel prologue) ...
     int n_long;                  // ... or 0 when there are none / too many to list (then every run is walked by its lane group)
     int node0;                   // first node of the bucket: f(source, destination - node0)
+    __device__ __forceinline__ bool can_stash(uint32_t) const { return false; }
+    template <typename F>
+    __device__ __forceinline__ void for_each_stash(uint32_t *, F &&) const {}
+    template <typename F>
+    __device__ __forceinline__ void replay(uint32_t *, uint32_t, F &&) const {}
     template <typename F>
     __device__ __forceinline__ void for_each(F &&f) const
     {
@@ -715,12 +347,20 @@ __device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds
         return;
     }
     dense.arrive();
+    SS_TICK_START();
     for (int i = threadIdx.x; i < nb; i += kFinishThreads) cnt[i] = 0;
     __syncthreads();
-    edges.for_each([&](int, int y) { atomicAdd(&cnt[y], 1u); });
+    // (workgroup-uniform) packed records of a bucket that fits the image: the counting sweep leaves them in the image array and the
+    // placing sweep takes them from there -- no second gather, no second run lookup (ppa-size finish: 9.3 us of 26.7 per workgroup)
+    const bool stashed = edges.can_stash(seg_n);
+    uint32_t *stash = reinterpret_cast<uint32_t *>(lds.image);
+    if (stashed) edges.for_each_stash(stash, [&](int, int y) { atomicAdd(&cnt[y], 1u); });
+    else edges.for_each([&](int, int y) { atomicAdd(&cnt[y], 1u); });
     __syncthreads();
+    SS_TICK(1);
     scan_bucket_nodes(cnt, excl, lds.wave_tot, nb, node0, N, seg_lo, seg_n, true, o);
     __syncthreads();
+    SS_TICK(2);
     // place the sources: node sub-ranges [n_lo, n_hi) whose edges fit the LDS image (one range when seg_n <= cap).
     // Every sub-range re-reads the whole segment, so a bucket far above the cap (hub-heavy buckets of power-law graphs)
     // is placed in ONE sweep straight into global memory instead: scattered 4-byte stores, but only for those buckets.
@@ -740,17 +380,21 @@ __device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds
         for (int i = n_lo + threadIdx.x; i < n_hi; i += kFinishThreads) cnt[i] = excl[i] - r_lo;  // cursors relative to the range
         __syncthreads();
         if (r_n > 0) {
-            edges.for_each([&](int x, int y) {
+            auto place = [&](int x, int y) {
                 if (y < n_lo || y >= n_hi) return;
                 const uint32_t pos = atomicAdd(&cnt[y], 1u);
                 if (direct) col[seg_lo + r_lo + pos] = x;
                 else lds.image[pos] = x;
-            });
+            };
+            if (stashed) edges.replay(stash, seg_n, place);  // (one range then: seg_n <= kFinishCap)
+            else edges.for_each(place);
             __syncthreads();
+            SS_TICK(3);
             if (!direct)
                 for (uint32_t q = threadIdx.x; q < r_n; q += kFinishThreads) col[seg_lo + r_lo + q] = lds.image[q];
         }
         __syncthreads();
+        SS_TICK(4);
         n_lo = n_hi;
     }
 }
@@ -795,14 +439,51 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
     int2 ed[PER];
     int key[PER];
     uint32_t rank[PER];
+    // All loads of a thread are issued before any is used, none under a per-edge branch: with `if (e < hi) { load; use; }` per edge
+    // the compiler put s_waitcnt vmcnt(0) behind every pair of loads -- eight load latencies in a row per tile.  Full tiles of
+    // 16-byte aligned rows read two edges per lane and load (global_load_dwordx4).
+    int64_t sv[PER], dv[PER];
+    bool ok[PER];
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    const bool vec = src && hi - t0 == kTile && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;  // (uniform)
+    if (vec) {
+        const i64x2 *src2 = reinterpret_cast<const i64x2 *>(src + t0), *dst2 = reinterpret_cast<const i64x2 *>(dst + t0);
+#pragma unroll
+        for (int k = 0; k < PER / 2; ++k) {
+            const i64x2 s2 = src2[threadIdx.x + k * kSortThreads], d2 = dst2[threadIdx.x + k * kSortThreads];
+            sv[2 * k] = s2.x; sv[2 * k + 1] = s2.y;
+            dv[2 * k] = d2.x; dv[2 * k + 1] = d2.y;
+            ok[2 * k] = ok[2 * k + 1] = true;
+        }
+    } else if (src) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int64_t e = t0 + threadIdx.x + (int64_t)k * kSortThreads;
+            ok[k] = e < hi;
+            sv[k] = src[ok[k] ? e : t0];  // (t0 < E: a valid entry for the lanes past the end)
+            dv[k] = dst[ok[k] ? e : t0];
+        }
+    } else {  // a link list: the key is the pair's first node, the "source" the pair's index (see fetch_edge)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int64_t e = t0 + threadIdx.x + (int64_t)k * kSortThreads;
+            ok[k] = e < hi;
+            sv[k] = ok[k] ? e : t0;
+            dv[k] = dst[2 * sv[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int64_t u = dv[k] < 0 ? dv[k] + N : dv[k];
+            dv[k] = (uint64_t)u < (uint64_t)N ? u : 0;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int64_t e = t0 + threadIdx.x + (int64_t)k * kSortThreads;
         key[k] = -1;
         ed[k] = make_int2(0, 0);
-        if (e < hi) {
-            int64_t s, d;
-            fetch_edge(src, dst, e, N, s, d);
+        if (ok[k]) {
+            int64_t s = sv[k];
+            const int64_t d = dv[k];
             const int64_t mx = s > d ? s : d;
             my_max = mx > my_max ? mx : my_max;
             if ((uint64_t)d >= (uint64_t)N) { bad = true; continue; }    // out of range: dropped (and reported)
@@ -1071,23 +752,6 @@ __device__ __forceinline__ void dense_helper(DenseLds &lds, int helper, int n_bu
 }
 
 static_assert(sizeof(DenseLds) <= sizeof(int32_t) * kFinishCap, "the helpers' LDS aliases the finish step's col image");
-
-__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const int2 *__restrict__ staged, const unsigned long long *__restrict__ fine_base,
-                                                                int node_shift, int64_t N, int32_t *__restrict__ col, RowOutputs o, DenseArgs dense,
-                                                                int64_t n_buckets)
-{
-    __shared__ FinishLds lds;
-    SS_CSR_SKIP(o.skip);
-    if ((int64_t)blockIdx.x >= n_buckets) {  // helper workgroup (see dense_helper)
-        dense_helper<false>(*reinterpret_cast<DenseLds *>(lds.image), (int)(blockIdx.x - n_buckets), (int)n_buckets, staged, nullptr, 0, node_shift,
-                            N, col, o, dense);
-        return;
-    }
-    const unsigned long long seg_lo = fine_base[blockIdx.x], seg_hi = fine_base[blockIdx.x + 1];
-    const uint32_t seg_n = (uint32_t)(seg_hi - seg_lo);
-    finish_bucket(ContiguousEdges{staged, seg_lo, seg_n, (int)((int64_t)blockIdx.x << node_shift)}, lds, seg_lo, seg_n, node_shift, N, col, o, dense);
-}
-
 
 __global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int2 *__restrict__ staged, const uint32_t *__restrict__ tile_off,
                                                                        const unsigned long long *__restrict__ tile_max, int tiles, int keys,
@@ -1430,8 +1094,8 @@ __global__ __launch_bounds__(kRegroupThreads) void regroup_sort_kernel(ParentLev
                                                                        const int32_t *__restrict__ skip)
 {
     __shared__ int2 sorted[kTile];
-    __shared__ int32_t run_start[kRegroupRuns + 1];
-    __shared__ uint32_t run_addr[kRegroupRuns];
+    __shared__ int32_t run_start[kRegroupRuns + 3];
+    __shared__ uint32_t run_delta[kRegroupRuns];  // first record of the run minus its first position
     __shared__ uint16_t first_run[kTile / kWave];
     __shared__ uint32_t tile_hist[kMaxKeys], tile_offs[kMaxKeys], wave_tot[kRegroupThreads / kWave];
     SS_CSR_SKIP(skip);
@@ -1453,10 +1117,11 @@ __global__ __launch_bounds__(kRegroupThreads) void regroup_sort_kernel(ParentLev
         const int R = t_hi - t_base < kRegroupRuns ? t_hi - t_base : kRegroupRuns;
         if ((int)threadIdx.x < R) {
             const int t = t_base + threadIdx.x;
-            run_start[threadIdx.x] = (int32_t)(P[t] - lo);  // (negative for the run the chunk begins inside of)
-            run_addr[threadIdx.x] = (par.tstart ? par.tstart[t] : (uint32_t)t * (uint32_t)kTile) + row0[t];
+            const int32_t st = (int32_t)(P[t] - lo);  // (negative for the run the chunk begins inside of)
+            run_start[threadIdx.x] = st;
+            run_delta[threadIdx.x] = (par.tstart ? par.tstart[t] : (uint32_t)t * (uint32_t)kTile) + row0[t] - (uint32_t)st;
         }
-        if (threadIdx.x == 0) run_start[R] = t_base + R < t_hi ? (int32_t)(P[t_base + R] - lo) : 0x7FFFFFFF;
+        if (threadIdx.x < 3) run_start[R + threadIdx.x] = threadIdx.x == 0 && t_base + R < t_hi ? (int32_t)(P[t_base + R] - lo) : 0x7FFFFFFF;
         __syncthreads();
         const int round_hi = run_start[R] < cnt ? run_start[R] : cnt;  // positions [round_lo, round_hi) lie in these runs
         if (threadIdx.x < kTile / kWave) {  // first run of every 64-position block: the last run that begins at or before it
@@ -1470,14 +1135,35 @@ __global__ __launch_bounds__(kRegroupThreads) void regroup_sort_kernel(ParentLev
             first_run[threadIdx.x] = (uint16_t)a;
         }
         __syncthreads();
+        // lookups, then loads, then selects -- none under a per-position branch (the compiler serialises loads behind such
+        // branches with s_waitcnt vmcnt(0): eight load latencies in a row); positions outside the round read a valid record
+        uint32_t rec[PER];
+        int run[PER];
+        bool more = false;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {  // (three independent boundary reads per position, no loop: the chains interleave)
+            int p = (int)threadIdx.x + k * kRegroupThreads;
+            p = p < round_lo ? round_lo : (p >= round_hi ? round_hi - 1 : p);
+            const int r0 = first_run[p / kWave];
+            const int b1 = run_start[r0 + 1], b2 = run_start[r0 + 2], b3 = run_start[r0 + 3];
+            more |= b3 <= p;
+            run[k] = r0 + (b1 <= p ? 1 : 0) + (b2 <= p ? 1 : 0) + (b3 <= p ? 1 : 0);
+            rec[k] = (uint32_t)p;
+        }
+        if (__builtin_expect(more, 0)) {  // runs shorter than ~20 edges
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                while (run_start[run[k] + 1] <= (int)rec[k]) ++run[k];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) rec[k] += run_delta[run[k]];
+        int2 got[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) got[k] = staged_in[rec[k]];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int p = (int)threadIdx.x + k * kRegroupThreads;
-            if (p >= round_lo && p < round_hi) {
-                int r = first_run[p / kWave];
-                while (run_start[r + 1] <= p) ++r;
-                ed[k] = staged_in[run_addr[r] + (uint32_t)(p - run_start[r])];
-            }
+            if (p >= round_lo && p < round_hi) ed[k] = got[k];
         }
         if (round_hi >= cnt) break;  // (workgroup-uniform)
         round_lo = round_hi;
@@ -1524,8 +1210,8 @@ __global__ __launch_bounds__(kRegroupThreads) void regroup_sort_kernel(ParentLev
 // ---- finish over runs ------------------------------------------------------------------------------------------------------------
 constexpr int kRunBlocks = (kDenseMin + kTile) / kWave;  // 64-position blocks of the largest bucket a workgroup walks itself
 struct RunLds {
-    uint32_t addr[kRunCap];            // first record of the run of each listed tile
-    uint16_t start[kRunCap + 2];       // exclusive prefix of the run lengths: position of each run's first edge; [n] = total
+    uint32_t delta[kRunCap];           // first record of the run of each listed tile MINUS the run's first position: record = delta + position
+    uint16_t start[kRunCap + 4];       // exclusive prefix of the run lengths: position of each run's first edge; [n] = total, then 0xFFFF
     uint16_t first_run[kRunBlocks + 2];  // the run that holds the first position of each 64-position block
     uint32_t wave_tot[kFinishThreads / kWave];
 };
@@ -1553,13 +1239,13 @@ struct RunEdges {
     __device__ __forceinline__ uint32_t prepare(int b0, int n, unsigned long long *o0_sum = nullptr) const
     {
         const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-        uint32_t len = 0;
+        uint32_t len = 0, addr = 0;
         if ((int)threadIdx.x < n) {
             const int t = b0 + threadIdx.x;
             const uint32_t o0 = row0[t];
             len = row1[t] - o0;
             if (o0_sum) *o0_sum += o0;
-            lds->addr[threadIdx.x] = (tstart ? tstart[t] : (uint32_t)t * (uint32_t)kTile) + o0;
+            addr = (tstart ? tstart[t] : (uint32_t)t * (uint32_t)kTile) + o0;
         }
         uint32_t inc = len;
 #pragma unroll
@@ -1574,8 +1260,11 @@ struct RunEdges {
             if (w < wv) pre += lds->wave_tot[w];
             total += lds->wave_tot[w];
         }
-        if ((int)threadIdx.x < n) lds->start[threadIdx.x] = (uint16_t)(pre + inc - len);
-        if (threadIdx.x == 0) lds->start[n] = (uint16_t)total;
+        if ((int)threadIdx.x < n) {
+            lds->start[threadIdx.x] = (uint16_t)(pre + inc - len);
+            lds->delta[threadIdx.x] = addr - (pre + inc - len);
+        }
+        if (threadIdx.x < 4) lds->start[n + threadIdx.x] = threadIdx.x == 0 ? (uint16_t)total : (uint16_t)0xFFFF;
         __syncthreads();
         // (a bucket above kDenseMin edges is not walked by its workgroup -- it goes to the dense steps, whose shares are walkable:
         // no table for it, its 16-bit starts are not used)
@@ -1592,46 +1281,99 @@ struct RunEdges {
         __syncthreads();
         return total;
     }
-    template <typename F>
-    __device__ __forceinline__ void walk(uint32_t total, F &&f) const
+    // the run of position p: the first run of p's 64-position block from the table (uniform over a wavefront), plus one for each of the
+    // next three run starts at or before p -- three independent reads, no loop: the positions' chains interleave (twelve while-loops of
+    // dependent LDS reads in a row were most of the 8.6 us a ppa-size bucket spent in a walk).  `more`: a fourth boundary may follow
+    // (runs shorter than ~20 edges), the caller finishes with advance()
+    __device__ __forceinline__ int run_of(uint32_t p, bool &more) const
     {
-        constexpr int U = PACKED ? 12 : 6;  // loads in flight per thread (a 12 K-edge bucket in one round)
+        const int r0 = lds->first_run[p / kWave];
+        const uint32_t b1 = lds->start[r0 + 1], b2 = lds->start[r0 + 2], b3 = lds->start[r0 + 3];
+        more |= b3 <= p;
+        return r0 + (b1 <= p ? 1 : 0) + (b2 <= p ? 1 : 0) + (b3 <= p ? 1 : 0);
+    }
+    __device__ __forceinline__ int advance(int r, uint32_t p) const
+    {
+        while (lds->start[r + 1] <= p) ++r;
+        return r;
+    }
+    // STASH (packed records, total <= kFinishCap): the records are also left in stash[position] -- see replay
+    template <bool STASH, typename F>
+    __device__ __forceinline__ void walk(uint32_t total, uint32_t *stash, F &&f) const
+    {
+        constexpr int U = PACKED ? 8 : 4;  // loads in flight per thread
         for (uint32_t p0 = 0; p0 < total; p0 += U * kFinishThreads) {
-            uint32_t v32[U];
+            // three stages, none of them under a per-position branch: with `if (p < total) { lookup; load; }` per position the compiler
+            // put s_waitcnt vmcnt(0) in front of every lookup -- twelve loads in a row, each waiting for the one before
+            uint32_t a[U], v32[U];
             int2 v64[U];
+            int r[U];
+            bool more = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t p = p0 + u * kFinishThreads + threadIdx.x;
-                if (p < total) {
-                    int r = lds->first_run[p / kWave];
-                    while (lds->start[r + 1] <= p) ++r;
-                    const uint32_t a = lds->addr[r] + (p - lds->start[r]);
-                    if (PACKED) v32[u] = reinterpret_cast<const uint32_t *>(staged)[a];
-                    else v64[u] = reinterpret_cast<const int2 *>(staged)[a];
-                }
+                a[u] = p < total ? p : total - 1;  // (a valid position for the lanes past the end; its record is not used)
+                r[u] = run_of(a[u], more);
+            }
+            if (__builtin_expect(more, 0)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) r[u] = advance(r[u], a[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u] += lds->delta[r[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (PACKED) v32[u] = reinterpret_cast<const uint32_t *>(staged)[a[u]];
+                else v64[u] = reinterpret_cast<const int2 *>(staged)[a[u]];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t p = p0 + u * kFinishThreads + threadIdx.x;
                 if (p < total) {
-                    if (PACKED) f((int)(v32[u] & ((1u << src_bits) - 1u)), (int)(v32[u] >> src_bits));
-                    else f(v64[u].x, v64[u].y - node0);
+                    if (PACKED) {
+                        if (STASH) stash[p] = v32[u];
+                        f((int)(v32[u] & ((1u << src_bits) - 1u)), (int)(v32[u] >> src_bits));
+                    } else {
+                        f(v64[u].x, v64[u].y - node0);
+                    }
                 }
             }
+        }
+    }
+    // can the first for_each leave the records in a kFinishCap-word LDS array for the second one?
+    __device__ __forceinline__ bool can_stash(uint32_t total) const { return PACKED && resident() && total <= (uint32_t)kFinishCap; }
+    template <typename F>
+    __device__ __forceinline__ void for_each_stash(uint32_t *stash, F &&f) const { walk<true>(lds->start[t_hi - t_lo], stash, f); }
+    // the stashed records again; f may overwrite the stash array (every thread holds its records in registers behind a barrier)
+    template <typename F>
+    __device__ __forceinline__ void replay(uint32_t *stash, uint32_t total, F &&f) const
+    {
+        constexpr int U = kFinishCap / kFinishThreads;
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = u * kFinishThreads + threadIdx.x;
+            if (p < total) v[u] = stash[p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = u * kFinishThreads + threadIdx.x;
+            if (p < total) f((int)(v[u] & ((1u << src_bits) - 1u)), (int)(v[u] >> src_bits));
         }
     }
     template <typename F>
     __device__ __forceinline__ void for_each(F &&f) const
     {
         if (resident()) {  // prepared by the caller
-            walk(lds->start[t_hi - t_lo], f);
+            walk<false>(lds->start[t_hi - t_lo], nullptr, f);
             return;
         }
         for (int b0 = t_lo; b0 < t_hi; b0 += kRunCap) {
             const int n = t_hi - b0 < kRunCap ? t_hi - b0 : kRunCap;
             __syncthreads();  // the walk of the batch before is done with the descriptors
             const uint32_t total = prepare(b0, n);
-            walk(total, f);
+            walk<false>(total, nullptr, f);
         }
     }
 };
@@ -1708,6 +1450,7 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
     __shared__ unsigned long long red_base[kFinishThreads / kWave], red_max[kFinishThreads / kWave];
     __shared__ uint32_t red_n[kFinishThreads / kWave];
     SS_CSR_SKIP(o.skip);
+    SS_TICK_START();
     const ChildGroup c = child_group(par, blockIdx.x);
     const uint32_t *row0 = par.off + (int64_t)c.k * par.tmax, *row1 = row0 + par.tmax;
     const int node0 = (int)((int64_t)blockIdx.x << node_shift);
@@ -1756,6 +1499,7 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
     dense.row1 = row1;
     dense.t_lo = c.t_lo;
     dense.t_hi = c.t_hi;
+    SS_TICK(0);
     finish_bucket(edges, lds, base, n, node_shift, N, col, o, dense);
 }
 
@@ -2008,41 +1752,45 @@ int helper_budget(Kernel kernel)
     return (int)(h > 0 ? h : 0);
 }
 
-inline int dense_helpers(bool gather)
+inline int dense_helpers()
 {
     static const bool launches = getenv("SS_CSR_DENSE") && !strcmp(getenv("SS_CSR_DENSE"), "launch");
-    // per device: a process may drive GPUs of different sizes
-    static int cache[2][64];
-    static bool known[2][64];
+    // per device: a process may drive GPUs of different sizes.  0 = not computed yet (a device whose budget IS 0 recomputes it
+    // every call: that path is the stand-alone launches and not performance critical); relaxed atomics: callers on several
+    // host threads may race to fill an entry, with the same value
+    static std::atomic<int> cache[64];
     int dev = 0;
     if (launches || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (!known[gather][dev]) {
-        cache[gather][dev] = gather ? helper_budget(finish_gather_kernel) : helper_budget(finish_kernel);
-        known[gather][dev] = true;
+    int h = cache[dev].load(std::memory_order_relaxed);
+    if (h == 0) {
+        h = helper_budget(finish_gather_kernel);
+        cache[dev].store(h, std::memory_order_relaxed);
     }
-    return cache[gather][dev];
+    return h;
 }
 
 }  // namespace ss
 
-// level plans take every shape the gather plan does not (SS_CSR_LEGACY=1: the round-3 partition passes, kept for A/B runs)
-static bool use_level_plan(const ss::CsrPlan &p, int64_t N, int64_t E, int64_t max_src, ss::LevelPlan &lp)
+#ifdef SS_CSR_TIMING
+extern "C" int ss_csr_timing_read(unsigned long long *out16, int reset)
 {
-    static const bool legacy = getenv("SS_CSR_LEGACY") != nullptr;
-    return !p.gather && !legacy && ss::make_level_plan(N, E, max_src, p.node_shift, lp);
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ss::csr_phase_ticks), 16 * 8) != hipSuccess) return SS_ERR_LAUNCH;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ss::csr_phase_ticks), z, 16 * 8) != hipSuccess) return SS_ERR_LAUNCH;
+    }
+    return SS_OK;
 }
+#endif
 
 extern "C" size_t ss_csr_workspace_bytes(int64_t N, int64_t E)
 {
     ss::CsrPlan p;
     if (!ss::make_plan(N, E, p)) return 0;
-    size_t bytes = ss::carve(p, E, nullptr).bytes;
+    if (p.gather) return ss::carve(p, E, nullptr).bytes;
     ss::LevelPlan lp;
-    if (ss::make_level_plan(N, E, N, p.node_shift, lp)) {
-        const size_t b = ss::carve_levels(lp, E, nullptr).bytes;
-        bytes = b > bytes ? b : bytes;
-    }
-    return bytes;
+    if (!ss::make_level_plan(N, E, N, p.node_shift, lp)) return 0;
+    return ss::carve_levels(lp, E, nullptr).bytes;
 }
 
 static int csr_build_levels(const ss::LevelPlan &lp, const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int32_t *col,
@@ -2186,25 +1934,26 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
     }
     ProfileSpan span(stream, SS_PROF_CSR);  // all launches of this build
     const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count, skip};
-    LevelPlan lp;
-    if (use_level_plan(p, N, E, src ? N : E, lp))
+    if (!p.gather) {  // level plans (1 - 3 tile-sort levels)
+        LevelPlan lp;
+        if (!make_level_plan(N, E, src ? N : E, p.node_shift, lp)) return SS_ERR_UNSUPPORTED;
         return csr_build_levels(lp, src, dst, E, N, col, reinterpret_cast<unsigned long long *>(n_self_loops_out), rows_out, hub_count,
                                 mega_count, err_flag, workspace, stream, skip, bad_record);
+    }
     const Workspace w = carve(p, E, workspace);
     unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
     // the dense steps loop over the registered shares: no more workgroups than shares can exist
     const int64_t share_cap = max_dense_shares(E);
     const unsigned dense_grid = (unsigned)(share_cap < kDenseGrid ? share_cap : kDenseGrid);
-    int helpers = dense_helpers(p.gather);
+    int helpers = dense_helpers();
     if ((int64_t)helpers > share_cap) helpers = (int)share_cap;
     const DenseArgs dense = {w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, helpers};
-
-    if (p.gather) {  // <= 256 fine buckets and <= kMaxTiles tiles: two launches, no counting pass, no scan kernels
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(p.tiles), dim3(kSortThreads), 0, stream, src, dst, E, N, p.shift1, p.keys1, p.tiles, w.staged_a,
+    {
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(p.tiles), dim3(kSortThreads), 0, stream, src, dst, E, N, p.node_shift, (int)p.fine_buckets, p.tiles, w.staged_a,
                            w.tile_off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip, bad_record);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(finish_gather_kernel, dim3((unsigned)(p.fine_buckets + helpers)), dim3(kFinishThreads), 0, stream, w.staged_a,
-                           w.tile_off, w.tile_max, p.tiles, p.keys1, p.node_shift, N, col, n_self, rows_out, dense);
+                           w.tile_off, w.tile_max, p.tiles, (int)p.fine_buckets, p.node_shift, N, col, n_self, rows_out, dense);
         SS_LAUNCH_CHECK();
         if (helpers) return SS_OK;
         hipLaunchKernelGGL(dense_count_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, w.staged_a, w.tile_off, p.tiles,
@@ -2215,69 +1964,4 @@ static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int
         SS_LAUNCH_CHECK();
         return SS_OK;
     }
-    // ---- pass 1 ----
-    PassArgs a1 = {};
-    a1.src = src; a1.dst = dst; a1.E = E; a1.N = N; a1.slice = p.slice1; a1.shift = p.shift1; a1.keys = p.keys1; a1.skip = skip; a1.bad_record = bad_record;
-    hipLaunchKernelGGL(count_keys_kernel<false>, dim3(p.blocks1), dim3(kThreads), 0, stream, a1, w.counts1, err_flag, n_self, hub_count,
-                       mega_count, w.dense_count);
-    SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_block_counts_kernel, dim3((p.keys1 + 3) / 4), dim3(kThreads), 0, stream, w.counts1, p.blocks1, p.keys1, w.base1, skip);
-    SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_bases_kernel, dim3(1), dim3(kThreads), 0, stream, w.base1, p.keys1, rowptr, N, skip);
-    SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scatter_tiles_kernel<false>, dim3(p.blocks1), dim3(kScatterThreads), 0, stream, a1, w.counts1, w.base1, w.staged_a, n_self,
-                       err_flag);
-    SS_LAUNCH_CHECK();
-    const int2 *final_staged = w.staged_a;
-    const unsigned long long *fine_base = w.base1;
-    // ---- pass 2 ----
-    if (p.two_pass) {
-        PassArgs a2 = {};
-        a2.staged = w.staged_a; a2.seg_base = w.base1; a2.N = N; a2.shift = p.shift1; a2.sub_shift = p.shift2; a2.keys = p.keys2;
-        a2.parts = p.parts2; a2.skip = skip;
-        const int64_t buckets2 = p.three_pass ? p.groups3 : p.fine_buckets;  // buckets that exist after pass 2
-        const unsigned blocks2 = (unsigned)(p.keys1 * p.parts2);
-        hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks2), dim3(kThreads), 0, stream, a2, w.counts2, (int32_t *)nullptr,
-                           (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-        SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scan_sub_counts_kernel, dim3(p.keys1), dim3(kThreads), 0, stream, w.counts2, p.keys2, p.parts2, w.base1,
-                           w.fine_base, buckets2, p.keys1, skip);
-        SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks2), dim3(kScatterThreads), 0, stream, a2, w.counts2, w.base1, w.staged_b,
-                           (unsigned long long *)nullptr, (int32_t *)nullptr);
-        SS_LAUNCH_CHECK();
-        final_staged = w.staged_b;
-        fine_base = w.fine_base;
-        // ---- pass 3 ----
-        if (p.three_pass) {
-            if (p.groups3 * p.parts3 >= ((int64_t)1 << 31)) return SS_ERR_UNSUPPORTED;
-            PassArgs a3 = {};
-            a3.staged = w.staged_b; a3.seg_base = w.fine_base; a3.N = N; a3.shift = p.shift2; a3.sub_shift = p.node_shift; a3.keys = p.keys3;
-            a3.parts = p.parts3; a3.skip = skip;
-            const unsigned blocks3 = (unsigned)(p.groups3 * p.parts3);
-            hipLaunchKernelGGL(count_keys_kernel<true>, dim3(blocks3), dim3(kThreads), 0, stream, a3, w.counts3, (int32_t *)nullptr,
-                               (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-            SS_LAUNCH_CHECK();
-            hipLaunchKernelGGL(scan_sub_counts_kernel, dim3((unsigned)p.groups3), dim3(kThreads), 0, stream, w.counts3, p.keys3, p.parts3,
-                               w.fine_base, w.fine_base3, p.fine_buckets, (int)p.groups3, skip);
-            SS_LAUNCH_CHECK();
-            hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(blocks3), dim3(kScatterThreads), 0, stream, a3, w.counts3, w.fine_base, w.staged_a,
-                               (unsigned long long *)nullptr, (int32_t *)nullptr);
-            SS_LAUNCH_CHECK();
-            final_staged = w.staged_a;
-            fine_base = w.fine_base3;
-        }
-    }
-    // ---- finish ----
-    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)(p.fine_buckets + helpers)), dim3(kFinishThreads), 0, stream, final_staged, fine_base,
-                       p.node_shift, N, col, rows_out, dense, p.fine_buckets);
-    SS_LAUNCH_CHECK();
-    if (helpers) return SS_OK;
-    hipLaunchKernelGGL(dense_count_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, final_staged, (const uint32_t *)nullptr, 0,
-                       p.node_shift, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, skip);
-    SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dense_place_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, final_staged, (const uint32_t *)nullptr, 0,
-                       p.node_shift, N, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, col, rows_out);
-    SS_LAUNCH_CHECK();
-    return SS_OK;
 }
