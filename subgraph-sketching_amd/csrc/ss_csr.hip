@@ -246,12 +246,12 @@ struct RowOutputs {
 };
 
 // exclusive scan of the per-node edge counts cnt[0..nb) of the bucket that starts at node0 -> excl[0..nb]; with `publish` the
-// row starts (rowptr) and the hub / mega rows of the bucket are written too.  Called by all kFinishThreads threads.
+// row starts (rowptr) and the hub / mega rows of the bucket are written too.  Called by all threads of the workgroup (1024 or 512).
 __device__ __forceinline__ void scan_bucket_nodes(const uint32_t *cnt, uint32_t *excl, uint32_t *wave_tot, int nb, int64_t node0, int64_t N,
                                                   unsigned long long seg_lo, uint32_t seg_n, bool publish, const RowOutputs &o)
 {
     // two counters per thread at nb = 1024
-    const int per = (nb + kFinishThreads - 1) / kFinishThreads;
+    const int per = (nb + (int)blockDim.x - 1) / (int)blockDim.x;
     const int b0 = threadIdx.x * per;
     uint32_t run = 0;
     for (int k = 0; k < per; ++k) run += (b0 + k < nb) ? cnt[b0 + k] : 0u;
@@ -317,7 +317,7 @@ struct DenseArgs {
         }
         __syncthreads();
         uint32_t *mine = node_cnt + (size_t)lds.wave_tot[0] * 1024;
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads) mine[i] = 0;
+        for (int i = threadIdx.x; i < nb; i += (int)blockDim.x) mine[i] = 0;
         if (helpers) {  // the helpers of THIS launch read the descriptor and add to the counters: publish (G16 producer form)
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -348,7 +348,7 @@ __device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds
     }
     dense.arrive();
     SS_TICK_START();
-    for (int i = threadIdx.x; i < nb; i += kFinishThreads) cnt[i] = 0;
+    for (int i = threadIdx.x; i < nb; i += (int)blockDim.x) cnt[i] = 0;
     __syncthreads();
     // (workgroup-uniform) packed records of a bucket that fits the image: the counting sweep leaves them in the image array and the
     // placing sweep takes them from there -- no second gather, no second run lookup (ppa-size finish: 9.3 us of 26.7 per workgroup)
@@ -377,7 +377,7 @@ __device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds
         const int n_hi = all_direct ? nb : lo_b;
         const uint32_t r_lo = excl[n_lo], r_n = excl[n_hi] - r_lo;
         const bool direct = r_n > (uint32_t)kFinishCap;  // single oversized node, or the whole oversized bucket
-        for (int i = n_lo + threadIdx.x; i < n_hi; i += kFinishThreads) cnt[i] = excl[i] - r_lo;  // cursors relative to the range
+        for (int i = n_lo + threadIdx.x; i < n_hi; i += (int)blockDim.x) cnt[i] = excl[i] - r_lo;  // cursors relative to the range
         __syncthreads();
         if (r_n > 0) {
             auto place = [&](int x, int y) {
@@ -386,12 +386,13 @@ __device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds
                 if (direct) col[seg_lo + r_lo + pos] = x;
                 else lds.image[pos] = x;
             };
-            if (stashed) edges.replay(stash, seg_n, place);  // (one range then: seg_n <= kFinishCap)
+            if (stashed)  // (one range then, the whole bucket: no range check)
+                edges.replay(stash, seg_n, [&](int x, int y) { lds.image[atomicAdd(&cnt[y], 1u)] = x; });
             else edges.for_each(place);
             __syncthreads();
             SS_TICK(3);
             if (!direct)
-                for (uint32_t q = threadIdx.x; q < r_n; q += kFinishThreads) col[seg_lo + r_lo + q] = lds.image[q];
+                for (uint32_t q = threadIdx.x; q < r_n; q += (int)blockDim.x) col[seg_lo + r_lo + q] = lds.image[q];
         }
         __syncthreads();
         SS_TICK(4);
@@ -1208,6 +1209,7 @@ __global__ __launch_bounds__(kRegroupThreads) void regroup_sort_kernel(ParentLev
 }
 
 // ---- finish over runs ------------------------------------------------------------------------------------------------------------
+constexpr int kRunThreads = 512;     // finish_runs_kernel: two workgroups per CU at 128 VGPRs, positions in steps of 512 (less padding than 1024)
 constexpr int kRunBlocks = (kDenseMin + kTile) / kWave;  // 64-position blocks of the largest bucket a workgroup walks itself
 struct RunLds {
     uint32_t delta[kRunCap];           // first record of the run of each listed tile MINUS the run's first position: record = delta + position
@@ -1218,36 +1220,45 @@ struct RunLds {
 static_assert(kDenseMin + kTile < 65536 && kDensePart + kTile < kDenseMin, "16-bit positions");
 
 // The runs (tile, k) of the tiles [t_lo, t_hi) as an edge source for finish_bucket / the dense steps, walked by POSITION: the edges
-// of the listed runs are numbered 0 .. total in tile order and thread i takes positions i, i + 1024, ...: every lane has an edge
+// of the listed runs are numbered 0 .. total in tile order and thread i takes positions i, i + THREADS, ...: every lane has an edge
 // whatever the run lengths are (16 lanes per 18-edge run left a quarter of them idle and a second dependent load for every run
 // above the lane group: 271 us for the ppa-size finish), a wavefront's 64 positions are consecutive records of one or two runs, and
-// all of a thread's loads are independent (eight in flight).  The run of a position: table lookup per 64-position block + a short
-// linear advance.  Up to kRunCap descriptors are resident in LDS; a longer range (a bucket under a heavily skewed parent group) is
-// walked batch by batch, reloading the descriptors in every for_each.  All threads call prepare / for_each (they contain barriers).
-template <bool PACKED>
+// a thread's loads are independent (eight in flight).  The run of a position: table lookup per 64-position block + up to three
+// boundary compares.  Up to kRunCap descriptors are resident in LDS; a longer range (a bucket under a heavily skewed parent group)
+// is walked batch by batch, reloading the descriptors in every for_each.  All threads call prepare / for_each / replay (barriers).
+// The kernel is bound by its VALU instruction count (PMC: 116 instructions per edge in the first version, VALUBusy 55 %), hence
+// the batches without bounds checks (FULL), the exact trip counts and the loop-free lookup.
+template <bool PACKED, int THREADS>
 struct RunEdges {
     const void *staged;
     const uint32_t *row0, *row1, *tstart;  // descriptor rows k and k + 1 (indexed by tile), tile starts (nullptr: t * kTile)
     int t_lo, t_hi;
     RunLds *lds;
     int src_bits, node0;
+    static constexpr int kPer = kRunCap / THREADS;  // descriptors per thread in prepare
 
     __device__ __forceinline__ bool resident() const { return t_hi - t_lo <= kRunCap; }
 
-    // descriptors of the tiles [b0, b0 + n), n <= kRunCap = kFinishThreads -> LDS; returns the number of edges in them
-    // (o0_sum: the thread's run offset inside its tile is added -- summed over the tiles of a group that is the bucket's start)
+    // descriptors of the tiles [b0, b0 + n), n <= kRunCap -> LDS; returns the number of edges in them
+    // (o0_sum: the thread's run offsets inside their tiles are added -- summed over the tiles of a group that is the bucket's start)
     __device__ __forceinline__ uint32_t prepare(int b0, int n, unsigned long long *o0_sum = nullptr) const
     {
         const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-        uint32_t len = 0, addr = 0;
-        if ((int)threadIdx.x < n) {
-            const int t = b0 + threadIdx.x;
-            const uint32_t o0 = row0[t];
-            len = row1[t] - o0;
-            if (o0_sum) *o0_sum += o0;
-            addr = (tstart ? tstart[t] : (uint32_t)t * (uint32_t)kTile) + o0;
+        uint32_t len[kPer], addr[kPer], run = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = threadIdx.x * kPer + j;
+            len[j] = addr[j] = 0;
+            if (i < n) {
+                const int t = b0 + i;
+                const uint32_t o0 = row0[t];
+                len[j] = row1[t] - o0;
+                if (o0_sum) *o0_sum += o0;
+                addr[j] = (tstart ? tstart[t] : (uint32_t)t * (uint32_t)kTile) + o0;
+            }
+            run += len[j];
         }
-        uint32_t inc = len;
+        uint32_t inc = run;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             const uint32_t x = __shfl_up(inc, off);
@@ -1256,20 +1267,27 @@ struct RunEdges {
         if (lane == kWave - 1) lds->wave_tot[wv] = inc;
         __syncthreads();
         uint32_t pre = 0, total = 0;
-        for (int w = 0; w < kFinishThreads / kWave; ++w) {
+#pragma unroll
+        for (int w = 0; w < THREADS / kWave; ++w) {
             if (w < wv) pre += lds->wave_tot[w];
             total += lds->wave_tot[w];
         }
-        if ((int)threadIdx.x < n) {
-            lds->start[threadIdx.x] = (uint16_t)(pre + inc - len);
-            lds->delta[threadIdx.x] = addr - (pre + inc - len);
+        uint32_t ex = pre + inc - run;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = threadIdx.x * kPer + j;
+            if (i < n) {
+                lds->start[i] = (uint16_t)ex;
+                lds->delta[i] = addr[j] - ex;
+            }
+            ex += len[j];
         }
         if (threadIdx.x < 4) lds->start[n + threadIdx.x] = threadIdx.x == 0 ? (uint16_t)total : (uint16_t)0xFFFF;
         __syncthreads();
         // (a bucket above kDenseMin edges is not walked by its workgroup -- it goes to the dense steps, whose shares are walkable:
         // no table for it, its 16-bit starts are not used)
         const uint32_t walkable = total <= (uint32_t)(kRunBlocks * kWave) ? total : 0u;
-        for (uint32_t q = threadIdx.x; q * kWave < walkable; q += kFinishThreads) {  // last run that begins at or before position 64 q
+        for (uint32_t q = threadIdx.x; q * kWave < walkable; q += THREADS) {  // last run that begins at or before position 64 q
             const uint32_t p0 = q * kWave;
             int a = 0, b = n;
             while (b - a > 1) {
@@ -1297,48 +1315,55 @@ struct RunEdges {
         while (lds->start[r + 1] <= p) ++r;
         return r;
     }
+    // positions p0 + u THREADS + thread, u < U.  Three stages, none of them under a per-position branch: with `if (p < total)
+    // { lookup; load; }` per position the compiler put s_waitcnt vmcnt(0) in front of every lookup -- U loads in a row, each waiting
+    // for the one before.  FULL: every position of the batch exists (no bounds checks at all).
     // STASH (packed records, total <= kFinishCap): the records are also left in stash[position] -- see replay
+    template <int U, bool FULL, bool STASH, typename F>
+    __device__ __forceinline__ void batch(uint32_t p0, uint32_t total, uint32_t *stash, F &&f) const
+    {
+        uint32_t a[U], v32[U];
+        int2 v64[U];
+        int r[U];
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = p0 + u * THREADS + threadIdx.x;
+            a[u] = FULL || p < total ? p : total - 1;  // (a valid position for the lanes past the end; its record is not used)
+            r[u] = run_of(a[u], more);
+        }
+        if (__builtin_expect(more, 0)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = advance(r[u], a[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] += lds->delta[r[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (PACKED) v32[u] = reinterpret_cast<const uint32_t *>(staged)[a[u]];
+            else v64[u] = reinterpret_cast<const int2 *>(staged)[a[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = p0 + u * THREADS + threadIdx.x;
+            if (FULL || p < total) {
+                if (PACKED) {
+                    if (STASH) stash[p] = v32[u];
+                    f((int)(v32[u] & ((1u << src_bits) - 1u)), (int)(v32[u] >> src_bits));
+                } else {
+                    f(v64[u].x, v64[u].y - node0);
+                }
+            }
+        }
+    }
     template <bool STASH, typename F>
     __device__ __forceinline__ void walk(uint32_t total, uint32_t *stash, F &&f) const
     {
         constexpr int U = PACKED ? 8 : 4;  // loads in flight per thread
-        for (uint32_t p0 = 0; p0 < total; p0 += U * kFinishThreads) {
-            // three stages, none of them under a per-position branch: with `if (p < total) { lookup; load; }` per position the compiler
-            // put s_waitcnt vmcnt(0) in front of every lookup -- twelve loads in a row, each waiting for the one before
-            uint32_t a[U], v32[U];
-            int2 v64[U];
-            int r[U];
-            bool more = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t p = p0 + u * kFinishThreads + threadIdx.x;
-                a[u] = p < total ? p : total - 1;  // (a valid position for the lanes past the end; its record is not used)
-                r[u] = run_of(a[u], more);
-            }
-            if (__builtin_expect(more, 0)) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) r[u] = advance(r[u], a[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) a[u] += lds->delta[r[u]];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (PACKED) v32[u] = reinterpret_cast<const uint32_t *>(staged)[a[u]];
-                else v64[u] = reinterpret_cast<const int2 *>(staged)[a[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t p = p0 + u * kFinishThreads + threadIdx.x;
-                if (p < total) {
-                    if (PACKED) {
-                        if (STASH) stash[p] = v32[u];
-                        f((int)(v32[u] & ((1u << src_bits) - 1u)), (int)(v32[u] >> src_bits));
-                    } else {
-                        f(v64[u].x, v64[u].y - node0);
-                    }
-                }
-            }
-        }
+        uint32_t p0 = 0;
+        for (; p0 + U * THREADS <= total; p0 += U * THREADS) batch<U, true, STASH>(p0, total, stash, f);
+        for (; p0 + 2 * THREADS <= total; p0 += 2 * THREADS) batch<2, true, STASH>(p0, total, stash, f);
+        if (p0 < total) batch<2, false, STASH>(p0, total, stash, f);
     }
     // can the first for_each leave the records in a kFinishCap-word LDS array for the second one?
     __device__ __forceinline__ bool can_stash(uint32_t total) const { return PACKED && resident() && total <= (uint32_t)kFinishCap; }
@@ -1348,19 +1373,27 @@ struct RunEdges {
     template <typename F>
     __device__ __forceinline__ void replay(uint32_t *stash, uint32_t total, F &&f) const
     {
-        constexpr int U = kFinishCap / kFinishThreads;
+        constexpr int U = kFinishCap / THREADS, C = 8;  // chunks of C positions: the ones past the bucket's end are skipped as a whole
         uint32_t v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t p = u * kFinishThreads + threadIdx.x;
-            if (p < total) v[u] = stash[p];
-        }
+        for (int c = 0; c < U; c += C)
+            if ((uint32_t)(c * THREADS) < total) {  // (uniform)
+#pragma unroll
+                for (int u = c; u < c + C; ++u) {
+                    const uint32_t p = u * THREADS + threadIdx.x;
+                    v[u] = stash[p < total ? p : 0];
+                }
+            }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t p = u * kFinishThreads + threadIdx.x;
-            if (p < total) f((int)(v[u] & ((1u << src_bits) - 1u)), (int)(v[u] >> src_bits));
-        }
+        for (int c = 0; c < U; c += C)
+            if ((uint32_t)(c * THREADS) < total) {
+#pragma unroll
+                for (int u = c; u < c + C; ++u) {
+                    const uint32_t p = u * THREADS + threadIdx.x;
+                    if (p < total) f((int)(v[u] & ((1u << src_bits) - 1u)), (int)(v[u] >> src_bits));
+                }
+            }
     }
     template <typename F>
     __device__ __forceinline__ void for_each(F &&f) const
@@ -1409,10 +1442,10 @@ struct DenseRunArgs {
         __syncthreads();
         const int d = (int)lds.excl[0], first = (int)lds.excl[1];
         uint32_t *mine = node_cnt + (size_t)d * 1024;
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads) mine[i] = 0;
+        for (int i = threadIdx.x; i < nb; i += (int)blockDim.x) mine[i] = 0;
         const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
         uint32_t carry = 0;
-        for (int t0 = t_lo; t0 < t_hi; t0 += kFinishThreads) {
+        for (int t0 = t_lo; t0 < t_hi; t0 += (int)blockDim.x) {
             const int t = t0 + threadIdx.x;
             const uint32_t len = t < t_hi ? row1[t] - row0[t] : 0u;
             uint32_t inc = len;
@@ -1425,7 +1458,7 @@ struct DenseRunArgs {
             if (lane == kWave - 1) lds.wave_tot[wv] = inc;
             __syncthreads();
             uint32_t pre = 0, tot = 0;
-            for (int w = 0; w < kFinishThreads / kWave; ++w) {
+            for (int w = 0; w < (int)blockDim.x / kWave; ++w) {
                 if (w < wv) pre += lds.wave_tot[w];
                 tot += lds.wave_tot[w];
             }
@@ -1439,7 +1472,7 @@ struct DenseRunArgs {
 };
 
 template <bool PACKED>
-__global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(8))) void finish_runs_kernel(ParentLevel par, const void *__restrict__ staged,
+__global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel par, const void *__restrict__ staged,
                                                                      const unsigned long long *__restrict__ tile_max, int tiles0, int node_shift,
                                                                      int src_bits, int64_t N, int32_t *__restrict__ col,
                                                                      unsigned long long *__restrict__ n_self, RowOutputs o, DenseRunArgs dense,
@@ -1447,14 +1480,14 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
 {
     __shared__ FinishLds lds;
     __shared__ RunLds runs;
-    __shared__ unsigned long long red_base[kFinishThreads / kWave], red_max[kFinishThreads / kWave];
-    __shared__ uint32_t red_n[kFinishThreads / kWave];
+    __shared__ unsigned long long red_base[kRunThreads / kWave], red_max[kRunThreads / kWave];
+    __shared__ uint32_t red_n[kRunThreads / kWave];
     SS_CSR_SKIP(o.skip);
     SS_TICK_START();
     const ChildGroup c = child_group(par, blockIdx.x);
     const uint32_t *row0 = par.off + (int64_t)c.k * par.tmax, *row1 = row0 + par.tmax;
     const int node0 = (int)((int64_t)blockIdx.x << node_shift);
-    const RunEdges<PACKED> edges{staged, row0, row1, par.tstart, c.t_lo, c.t_hi, &runs, src_bits, node0};
+    const RunEdges<PACKED, kRunThreads> edges{staged, row0, row1, par.tstart, c.t_lo, c.t_hi, &runs, src_bits, node0};
     unsigned long long base = 0, mx = 0;
     uint32_t n = 0;
     const bool resident = edges.resident();  // (workgroup-uniform) one descriptor per thread: loaded once, for the sums and the walks
@@ -1462,14 +1495,14 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
         const uint32_t total = edges.prepare(c.t_lo, c.t_hi - c.t_lo, &base);
         n = threadIdx.x == 0 ? total : 0u;
     } else {
-        for (int t = c.t_lo + threadIdx.x; t < c.t_hi; t += kFinishThreads) {
+        for (int t = c.t_lo + threadIdx.x; t < c.t_hi; t += kRunThreads) {
             const uint32_t o0 = row0[t];
             base += o0;
             n += row1[t] - o0;
         }
     }
     if (blockIdx.x == 0)  // the first workgroup also reduces max(edge_index) + 1 (the self-loop count, hashing.py:148)
-        for (int t = threadIdx.x; t < tiles0; t += kFinishThreads) {
+        for (int t = threadIdx.x; t < tiles0; t += kRunThreads) {
             const unsigned long long v = tile_max[t];
             mx = v > mx ? v : mx;
         }
@@ -1486,7 +1519,7 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
     }
     __syncthreads();
     base = c.base, n = 0, mx = 0;
-    for (int w = 0; w < kFinishThreads / kWave; ++w) {
+    for (int w = 0; w < kRunThreads / kWave; ++w) {
         base += red_base[w];
         n += red_n[w];
         mx = red_max[w] > mx ? red_max[w] : mx;
@@ -1513,7 +1546,7 @@ struct DenseRunLds {
 
 // (all threads; barriers) the bucket of share `item` and its tile range; the descriptors of the range (or of its first batch) -> LDS
 template <bool PACKED>
-__device__ __forceinline__ RunEdges<PACKED> locate_run_share(DenseRunLds &lds, int item, int n_dense, const DenseRunBucket *__restrict__ list,
+__device__ __forceinline__ RunEdges<PACKED, kFinishThreads> locate_run_share(DenseRunLds &lds, int item, int n_dense, const DenseRunBucket *__restrict__ list,
                                                                  const uint32_t *__restrict__ share_lo, const ParentLevel &par,
                                                                  const void *__restrict__ staged, int node_shift, int src_bits, DenseRunBucket &b)
 {
@@ -1528,7 +1561,7 @@ __device__ __forceinline__ RunEdges<PACKED> locate_run_share(DenseRunLds &lds, i
     const int t_lo = (int)share_lo[item], t_hi = s + 1 < b.shares ? (int)share_lo[item + 1] : b.t_hi;
     const ChildGroup c = child_group(par, b.bucket);
     const uint32_t *row0 = par.off + (int64_t)c.k * par.tmax, *row1 = row0 + par.tmax;
-    RunEdges<PACKED> e{staged, row0, row1, par.tstart, t_lo, t_hi, &lds.runs, src_bits, (int)((int64_t)b.bucket << node_shift)};
+    RunEdges<PACKED, kFinishThreads> e{staged, row0, row1, par.tstart, t_lo, t_hi, &lds.runs, src_bits, (int)((int64_t)b.bucket << node_shift)};
     if (e.resident()) e.prepare(t_lo, t_hi - t_lo);
     return e;
 }
@@ -1545,7 +1578,7 @@ __global__ __launch_bounds__(kFinishThreads) void dense_count_runs_kernel(Parent
     const int n_dense = dense_count[0], n_shares = dense_count[1], nb = 1 << node_shift;
     for (int item = blockIdx.x; item < n_shares; item += gridDim.x) {
         DenseRunBucket b;
-        const RunEdges<PACKED> edges = locate_run_share<PACKED>(lds, item, n_dense, list, share_lo, par, staged, node_shift, src_bits, b);
+        const RunEdges<PACKED, kFinishThreads> edges = locate_run_share<PACKED>(lds, item, n_dense, list, share_lo, par, staged, node_shift, src_bits, b);
         for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = 0;
         __syncthreads();
         edges.for_each([&](int, int y) { atomicAdd(&lds.cnt[y], 1u); });
@@ -1572,7 +1605,7 @@ __global__ __launch_bounds__(kFinishThreads) void dense_place_runs_kernel(Parent
     const int n_dense = dense_count[0], n_shares = dense_count[1], nb = 1 << node_shift;
     for (int item = blockIdx.x; item < n_shares; item += gridDim.x) {
         DenseRunBucket b;
-        const RunEdges<PACKED> edges = locate_run_share<PACKED>(lds, item, n_dense, list, share_lo, par, staged, node_shift, src_bits, b);
+        const RunEdges<PACKED, kFinishThreads> edges = locate_run_share<PACKED>(lds, item, n_dense, list, share_lo, par, staged, node_shift, src_bits, b);
         const uint32_t *total = node_cnt + (size_t)lds.desc * 1024;
         // (the totals were formed by other workgroups' agent-scope atomics in the launch before)
         for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = total[i];
@@ -1836,7 +1869,7 @@ static int csr_build_levels(const ss::LevelPlan &lp, const int64_t *src, const i
     const int64_t share_cap = max_dense_shares(E);
     const unsigned dense_grid = (unsigned)(share_cap < kDenseGrid ? share_cap : kDenseGrid);
     if (packed) {
-        hipLaunchKernelGGL(finish_runs_kernel<true>, dim3((unsigned)fine), dim3(kFinishThreads), 0, stream, par, in, w.tile_max, tiles0,
+        hipLaunchKernelGGL(finish_runs_kernel<true>, dim3((unsigned)fine), dim3(kRunThreads), 0, stream, par, in, w.tile_max, tiles0,
                            lp.node_shift, lp.src_bits, N, col, n_self, rows_out, dense, fine);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(dense_count_runs_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, par, in, lp.node_shift, lp.src_bits,
@@ -1846,7 +1879,7 @@ static int csr_build_levels(const ss::LevelPlan &lp, const int64_t *src, const i
                            w.dense_count, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, col, rows_out);
         SS_LAUNCH_CHECK();
     } else {
-        hipLaunchKernelGGL(finish_runs_kernel<false>, dim3((unsigned)fine), dim3(kFinishThreads), 0, stream, par, in, w.tile_max, tiles0,
+        hipLaunchKernelGGL(finish_runs_kernel<false>, dim3((unsigned)fine), dim3(kRunThreads), 0, stream, par, in, w.tile_max, tiles0,
                            lp.node_shift, lp.src_bits, N, col, n_self, rows_out, dense, fine);
         SS_LAUNCH_CHECK();
         hipLaunchKernelGGL(dense_count_runs_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, par, in, lp.node_shift, lp.src_bits,
