@@ -3,23 +3,35 @@
 // The reference materialises one message x[src] per edge and scatter-maxes it (PyG propagate,
 // hashing.py:34,44).  The MI355X engine instead pulls: edges are grouped by destination once and every
 // hop streams whole neighbour rows.  The order of sources inside a row is unspecified (min / max do not
-// care), which lets the build be an MSD radix partition with
+// care), which lets the build be an MSD radix sort with
 //   * NO per-edge global atomics -- device-scope atomics from 8 non-coherent XCD L2s are served at the memory
-//     side (first version: 0.23 ms for 2.4 M edges), and
+//     side (first version: 0.23 ms for 2.4 M edges),
 //   * NO scattered small stores -- an 8-byte store per edge into hundreds of open segments reaches the memory side
-//     as 3-5x its useful bytes (second version, PMC: 1.09 GB written for 0.34 GB on a ppa-sized graph).  Every
-//     partition step sorts a 4096-edge tile by key in LDS first and writes it out as contiguous runs.
+//     as 3-5x its useful bytes (second version, PMC: 1.09 GB written for 0.34 GB on a ppa-sized graph): every
+//     step sorts a 4096-edge tile by key in LDS first and writes it back as ONE contiguous tile, and
+//   * NO counting pass over the edges and NO scan over counters (third version: two counting kernels that re-read the
+//     edges and three scans per partition pass, 3.6x the algorithmic traffic at ogbl-ppa / -citation2 size): a sorted tile
+//     needs no global offsets -- it is located through its exclusive key offsets off[key][tile] ("run descriptors").
 //
 // A "fine bucket" is 2^node_shift consecutive destination nodes (<= 1024, fewer for dense graphs so that a bucket's
-// edges fit the LDS staging buffer of the last step).
-//   gather plan  (<= 256 fine buckets, <= 1536 tiles: every shape up to ogbl-collab size) tile_sort -> finish_gather, two launches
-//   level plans  (everything else) 1 - 3 tile-sort levels read through run descriptors -> finish_runs (see "level plans" below)
-//   finish       one workgroup per fine bucket: LDS histogram over its nodes, LDS scan -> rowptr, sources placed into an
-//                LDS image of the bucket's col segment and streamed out (oversized buckets: several node sub-ranges; dense
-//                buckets: split over several workgroups)
-// No counting pass over the edges and no scan over counters anywhere: the sorted tiles are written in place and located through
-// their per-tile key offsets.  The first level also validates ids and reduces max(id)+1 (the self-loop count of add_self_loops,
-// hashing.py:148); the finish step lists hub rows.  Nothing synchronises with the host.
+// edges fit the LDS image of the last step), reached by 1 - 3 tile-sort LEVELS of at most 256 keys each:
+//   level 0   tile_sort_kernel     edges (16 B) -> tiles of (src, dst) int2 keyed by the top bits of dst, off0
+//   level l   regroup_sort_kernel  the input of group G = (parent group g, key k) is the VIRTUAL concatenation of the runs
+//                                  (tile, k) over the tiles of g, read through the descriptors and cut into 4096-edge chunks:
+//                                  chunk c of G becomes tile (G, c) of this level, keyed by the next bits of dst
+//   finish    finish_runs_kernel   one workgroup per fine bucket: its runs gathered from the tiles of its parent group, LDS
+//                                  histogram over its nodes, LDS scan -> rowptr, sources placed into an LDS image of the
+//                                  bucket's col segment and streamed out.  The start of the bucket in col is
+//                                  base[g] + sum over those tiles of off[k][tile]: no scan kernel, no global counters.
+//                                  Buckets above the image (node ids correlated with degree) are split over several workgroups.
+// The records of the LAST level are packed, src | (dst & (2^node_shift - 1)) << src_bits (4 bytes), when the ids fit.
+// What is needed between two levels is small: per (g, k) a prefix of the run lengths over the tiles and the first tile of
+// every chunk (level_scan_kernel), the tile ranges of the groups (level_tiles_kernel) and a header per tile
+// (level_fill_kernel) -- descriptor-sized arrays.  One level up to ogbl-collab size (2 launches), two up to 65 536 fine
+// buckets (ogbl-ppa, ogbl-citation2), three beyond (N > 67 M nodes, or a few million nodes of a very dense graph).
+// Traffic per edge at two levels: 16 + 8 (level 0) + 8 + 4 (level 1) + 4 + 4 (finish) = 44 B against 20 B algorithmic.
+// The first level also validates ids and reduces max(id)+1 (the self-loop count of add_self_loops, hashing.py:148);
+// the finish step lists hub rows.  Nothing synchronises with the host.
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -30,100 +42,105 @@ namespace ss {
 
 constexpr int kTile = 4096;            // edges sorted in LDS at a time by a tile-sort level
 constexpr int kMaxKeys = 256;          // fan-out of a tile-sort level
-constexpr int kFinishThreads = 1024;      // (512: bench graph 46-48 us, rank^-0.5 133-137, rank^-0.9 640; 1024: 45, 121, 567)
-constexpr int kFinishCap = 16384;      // edges staged in LDS by the finish step (64 KiB)
-constexpr int kMaxTiles = 1536;        // gather plan: tiles whose run descriptors fit the finish step's LDS beside the image (2 workgroups per CU)
+constexpr int kMaxLevels = 3;
+constexpr int kSortThreads = 512;      // level 0: 8 edges per thread (256 threads x 16 edges: 19.3 us on the collab-like graph, 512 x 8: 16.1 us)
+constexpr int kRegroupThreads = 512;   // levels >= 1
+constexpr int kRegroupRuns = 512;      // run descriptors a regroup workgroup holds at a time (more: further rounds)
+constexpr int kRunThreads = 512;       // finish: two workgroups per CU at 128 VGPRs, positions in steps of 512 (less padding than 1024)
+constexpr int kDenseThreads = 1024;    // the stand-alone dense launches
+constexpr int kFinishCap = 16384;      // edges of a bucket's col image in LDS (64 KiB)
+constexpr int kRunCap = 1024;          // run descriptors the finish step keeps in LDS (two workgroups per CU: 80 KB each)
 // Dense fine buckets (node ids correlated with degree: power-law graphs put 5 - 40 % of the edges into the first 1024 nodes) are
-// NOT finished by their one workgroup -- a single CU reading the segment twice was the whole build on such graphs (532 us of a
-// 1.23 ms step at rank^-0.9 endpoints, 97 us at rank^-0.5 against 21 us uniform).  The finish launch only registers them; two
-// further steps split each by EDGES over several workgroups: dense_count (LDS histogram of a share, ONE global atomic per
-// touched node and share: its return value is the share's offset inside the node's row) and dense_place (row starts from the
-// summed counters, sources stored at start + share offset + LDS cursor).  Both exit at once when nothing was registered.
-constexpr int kDenseMin = 32768;       // a fine bucket with more edges than this is split ...
-constexpr int kDensePart = 16384;      // ... into shares of about this many edges
+// NOT finished by their one workgroup -- a single CU walking such a segment was the whole build on those graphs (532 us of a
+// 1.23 ms step at rank^-0.9 endpoints).  The finish launch only registers every bucket that does not fit the image; two further
+// steps split each over several workgroups by TILE ranges of about kDensePart edges (a run is at most a tile long, so tile
+// granularity balances the shares): dense_count (LDS histogram of a share, ONE global atomic per touched node and share: its
+// return value is the share's offset inside the node's row) and dense_place (row starts from the summed counters, sources stored
+// at start + share offset + LDS cursor).  (Walking a bucket of up to two images in node sub-ranges, re-reading it for each, as
+// round 3 did: 61 us instead of 23 for the finish launch of a collab-size graph with rank^-0.5 endpoints.)
+constexpr int kDenseMin = kFinishCap;  // a fine bucket with more edges than this is split ...
+constexpr int kDensePart = 8192;       // ... into shares of about this many edges
 constexpr int kDenseGrid = 1024;       // workgroups of the two dense launches (each loops over the shares)
 // dense_count words: [0] dense buckets, [1] shares, [3] helpers done counting, [kArriveBase + 16 k] (k < kArriveWords, one cache
 // line each) fine buckets whose workgroup has decided -- 64 sharded words: one word takes ~90 atomics per microsecond
 constexpr int kArriveBase = 16, kArriveWords = 64, kDenseSyncInts = kArriveBase + 16 * kArriveWords;
 
-struct CsrPlan {
-    int node_shift;       // fine bucket = dst >> node_shift
-    int64_t fine_buckets;
-    bool gather;          // <= 256 fine buckets and <= kMaxTiles tiles: two launches, tile_sort_kernel + finish_gather_kernel
-    int tiles;            // 4096-edge tiles
-};
-
-// average edges of a fine bucket the level plans aim for.  The finish step stages kFinishCap = 16 384 edges in LDS; a bucket
-// above that takes node sub-ranges, above kDenseMin it is split by edges over several workgroups -- which is why the target can sit
-// at 3/4 of the cap instead of 1/2: half as many finish workgroups, each with the same fixed latencies.  SS_CSR_BUCKET_EDGES: tuning hook
+// average edges of a fine bucket the plans aim for: 3/4 of the image (a bucket above it goes to the dense steps, at some cost;
+// half as many finish workgroups as at 1/2, each with the same fixed latencies).  SS_CSR_BUCKET_EDGES: tuning hook
 inline int64_t bucket_edges_target()
 {
     static const int64_t env = getenv("SS_CSR_BUCKET_EDGES") ? atoll(getenv("SS_CSR_BUCKET_EDGES")) : 0;
     return env > 0 ? env : kFinishCap * 3 / 4;
 }
 
-inline bool make_plan(int64_t N, int64_t E, CsrPlan &p)
+struct LevelPlan {
+    int levels;
+    int node_shift;                 // fine bucket = dst >> node_shift
+    int shift[kMaxLevels];          // level l keys on dst >> shift[l]; shift[levels - 1] == node_shift
+    int keys[kMaxLevels];           // fan-out (level 0: ceil(N / 2^shift[0]) <= 256; below: powers of two <= 256)
+    int log2_keys[kMaxLevels];      // -1 at level 0
+    int64_t groups[kMaxLevels + 1]; // groups[l]: groups at the INPUT of level l (groups[0] = 1); groups[levels]: fine buckets
+    int64_t tmax[kMaxLevels];       // tile slots of level l (row stride of its descriptor arrays)
+    bool packed;                    // records of the last level are 4 bytes
+    int src_bits;                   // 32 - node_shift
+};
+
+inline int ceil_log2_i64(int64_t x)
+{
+    int b = 0;
+    while (((int64_t)1 << b) < x) ++b;
+    return b;
+}
+
+// max_src: sources are < max_src (N for edge lists, B for link lists)
+inline bool make_plan(int64_t N, int64_t E, int64_t max_src, LevelPlan &p)
 {
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31)) return false;
+    if (E >= ((int64_t)1 << 32) - 2 * kTile) return false;  // record indices are 32-bit
     const int64_t n = N > 0 ? N : 1;
-    // fine bucket = 1024 nodes when that gives <= 256 buckets (one tile-sort level; the finish step copes with dense buckets
-    // through node sub-ranges and the dense steps); otherwise a bucket sized for about 3/4 kFinishCap edges on average, between 64
-    // and 1024 nodes, reached by two or three levels
-    int shift = 10;
+    // fine bucket = 1024 nodes when that gives <= 256 buckets (one level); otherwise a bucket sized for about 3/4 kFinishCap
+    // edges on average, between 64 and 1024 nodes
+    int node_shift = 10;
     if (((n + 1023) >> 10) > kMaxKeys)
-        while (shift > 6 && (E / n) * ((int64_t)1 << shift) > bucket_edges_target()) --shift;
+        while (node_shift > 6 && (E / n) * ((int64_t)1 << node_shift) > bucket_edges_target()) --node_shift;
     if (const char *forced = getenv("SS_CSR_NODE_SHIFT")) {  // test hook: reach the three-level plans with small graphs
         const int f = atoi(forced);
-        if (f >= 4 && f <= 10) shift = f;
+        if (f >= 4 && f <= 10) node_shift = f;
     }
-    p.node_shift = shift;
-    p.fine_buckets = (n + ((int64_t)1 << shift) - 1) >> shift;
-    p.tiles = (int)((E + kTile - 1) / kTile);
-    // SS_CSR_NO_GATHER: test hook, small graphs through the one-level plan of the level builder
-    p.gather = p.fine_buckets <= kMaxKeys && E > 0 && (E + kTile - 1) / kTile <= kMaxTiles && !getenv("SS_CSR_NO_GATHER");
+    const int64_t fine = (n + ((int64_t)1 << node_shift) - 1) >> node_shift;
+    const int tb = ceil_log2_i64(fine);
+    if (tb > 24) return false;
+    p.node_shift = node_shift;
+    p.levels = fine <= kMaxKeys ? 1 : (tb <= 16 ? 2 : 3);
+    int below[kMaxLevels] = {0, 0, 0};  // key bits of the levels under level 0: split evenly (run lengths 4096 / keys per level)
+    if (p.levels == 2) below[1] = tb / 2;
+    if (p.levels == 3) { below[2] = tb / 3; below[1] = (tb - below[2]) / 2; }
+    int s = node_shift;
+    for (int l = p.levels - 1; l >= 1; --l) {
+        p.shift[l] = s;
+        p.keys[l] = 1 << below[l];
+        p.log2_keys[l] = below[l];
+        s += below[l];
+    }
+    p.shift[0] = s;
+    p.keys[0] = (int)((n + ((int64_t)1 << s) - 1) >> s);
+    p.log2_keys[0] = -1;
+    if (p.keys[0] > kMaxKeys) return false;
+    const int64_t tiles0 = (E + kTile - 1) / kTile;
+    p.groups[0] = 1;
+    p.tmax[0] = tiles0 > 0 ? tiles0 : 1;
+    for (int l = 1; l <= p.levels; ++l) {
+        p.groups[l] = (n + ((int64_t)1 << p.shift[l - 1]) - 1) >> p.shift[l - 1];
+        if (l < p.levels) p.tmax[l] = tiles0 + p.groups[l];
+    }
+    p.src_bits = 32 - node_shift;
+    p.packed = max_src <= ((int64_t)1 << p.src_bits) && !getenv("SS_CSR_NO_PACK");  // (SS_CSR_NO_PACK: test hook, 8-byte records)
     return true;
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-struct DenseBucket {  // a fine bucket left to the dense steps (gather plan)
-    int32_t bucket, first_share, shares;
-    uint32_t n;                 // edges
-    unsigned long long base;    // start of the bucket in col
-};
-
-struct Workspace {  // gather plan
-    unsigned long long *scratch;    // [1] n_self when the caller does not want it
-    int2 *staged_a;                 // [E]
-    uint32_t *tile_off;             // [fine_buckets + 1][tiles]
-    unsigned long long *tile_max;   // [tiles]
-    int32_t *dense_count;           // [kDenseSyncInts]
-    DenseBucket *dense_list;        // [max_dense]
-    uint32_t *dense_node_cnt;       // [max_dense][1024] edges per node of a dense bucket
-    uint32_t *dense_share_off;      // [max_shares][1024] offset of a share's edges inside each node's row
-    size_t bytes;
-};
-
 inline int64_t max_dense_buckets(int64_t E) { return E / kDenseMin + 1; }
 inline int64_t max_dense_shares(int64_t E) { return E / kDensePart + max_dense_buckets(E) + 1; }
-
-inline Workspace carve(const CsrPlan &p, int64_t E, void *base)
-{
-    Workspace w;
-    char *c = reinterpret_cast<char *>(base);
-    size_t off = 0;
-    auto take = [&](size_t n) { char *r = c ? c + off : nullptr; off += align256(n); return r; };
-    w.scratch = reinterpret_cast<unsigned long long *>(take(8));
-    w.staged_a = reinterpret_cast<int2 *>(take((size_t)(E > 0 ? E : 1) * 8));
-    w.tile_off = reinterpret_cast<uint32_t *>(take((size_t)(p.fine_buckets + 1) * p.tiles * 4));
-    w.tile_max = reinterpret_cast<unsigned long long *>(take((size_t)p.tiles * 8));
-    w.dense_count = reinterpret_cast<int32_t *>(take(4 * kDenseSyncInts));
-    w.dense_list = reinterpret_cast<DenseBucket *>(take((size_t)max_dense_buckets(E) * sizeof(DenseBucket)));
-    w.dense_node_cnt = reinterpret_cast<uint32_t *>(take((size_t)max_dense_buckets(E) * 1024 * 4));
-    w.dense_share_off = reinterpret_cast<uint32_t *>(take((size_t)max_dense_shares(E) * 1024 * 4));
-    w.bytes = off;
-    return w;
-}
 
 // ---- block-wide exclusive scan of the 256 key counters inside a workgroup of THREADS >= 256 threads: thread k < 256 owns key k, the other
 // wavefronts contribute zeros (tile sort / regroup run 512 threads per 4096-edge tile: 8 edges per thread)
@@ -173,247 +190,16 @@ __device__ unsigned long long csr_phase_ticks[16];
 #define SS_TICK_START()
 #endif
 
-// ---- finish: one workgroup per fine bucket --------------------------------------------------------------------------------
-// The bucket's edges reach the workgroup through an "edge source" with for_each(f): one short run per 4096-edge tile of the
-// tile-sorted array (gather plan: GatheredEdges, see tile_sort_kernel; level plans: RunEdges).
-// LANES lanes read one tile's run; chosen from the average run length of the bucket (tile / buckets = ~18 edges on the bench
-// graph -> 32 lanes; skewed buckets whose runs are hundreds of edges -> whole wavefronts), so that most runs need one load
-constexpr int kLongRun = 256;   // runs above this many edges (a SORTED stretch of the edge list -- e.g. the self loops ELPH
-constexpr int kLongCap = 128;   // appends, models/elph.py:186 -- puts a whole bucket into one tile) are walked by the whole workgroup
-template <int LANES>
-struct GatheredEdges {
-    const int2 *staged;
-    const uint32_t *seg;  // LDS [tiles]: run start inside the tile (low 16 bits) | run length << 16
-    int tiles;
-    const uint16_t *long_tiles;  // LDS: tiles whose run is longer than kLongRun (listed by the kernel prologue) ...
-    int n_long;                  // ... or 0 when there are none / too many to list (then every run is walked by its lane group)
-    int node0;                   // first node of the bucket: f(source, destination - node0)
-    __device__ __forceinline__ bool can_stash(uint32_t) const { return false; }
-    template <typename F>
-    __device__ __forceinline__ void for_each_stash(uint32_t *, F &&) const {}
-    template <typename F>
-    __device__ __forceinline__ void replay(uint32_t *, uint32_t, F &&) const {}
-    template <typename F>
-    __device__ __forceinline__ void for_each(F &&f) const
-    {
-        constexpr int kGroups = kFinishThreads / LANES;
-        const int grp = threadIdx.x / LANES, l = threadIdx.x % LANES;
-        const uint32_t skip_above = n_long ? (uint32_t)kLongRun : 0xFFFFFFFFu;
-        for (int k = 0; k < n_long; ++k) {  // long runs: all threads, coalesced
-            const int t = long_tiles[k];
-            const uint32_t d = seg[t];
-            const int2 *run = staged + (int64_t)t * kTile + (d & 0xFFFFu);
-            for (uint32_t q = threadIdx.x; q < (d >> 16); q += kFinishThreads) {
-                const int2 v = run[q];
-                f(v.x, v.y - node0);
-            }
-        }
-        for (int t0 = grp; t0 < tiles; t0 += 4 * kGroups) {  // four runs requested per lane group before the first is consumed
-            int2 v[4];
-            uint32_t len[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int t = t0 + k * kGroups;
-                const uint32_t d = t < tiles ? seg[t] : 0u;
-                len[k] = (d >> 16) > skip_above ? 0u : d >> 16;
-                v[k] = (uint32_t)l < len[k] ? staged[(int64_t)t * kTile + (d & 0xFFFFu) + l] : make_int2(0, -1);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (v[k].y >= 0) f(v[k].x, v[k].y - node0);
-                if (len[k] > (uint32_t)LANES) {  // the rest of a run longer than the lane group, two loads in flight
-                    const int t = t0 + k * kGroups;
-                    const int2 *run = staged + (int64_t)t * kTile + (seg[t] & 0xFFFFu);
-                    for (uint32_t q = LANES + l; q < len[k]; q += 2 * LANES) {
-                        const int2 a = run[q];
-                        const int2 b = q + LANES < len[k] ? run[q + LANES] : make_int2(0, -1);
-                        f(a.x, a.y - node0);
-                        if (b.y >= 0) f(b.x, b.y - node0);
-                    }
-                }
-            }
-        }
-    }
-};
-
-
-// what the finish step writes besides col: rowptr and the hub / mega row lists
-struct RowOutputs {
-    int64_t *rowptr;
-    int hub_threshold;
-    int32_t *hub_rows, *hub_count, *mega_rows, *mega_count;
-    const int32_t *skip;  // see PassArgs
-};
-
-// exclusive scan of the per-node edge counts cnt[0..nb) of the bucket that starts at node0 -> excl[0..nb]; with `publish` the
-// row starts (rowptr) and the hub / mega rows of the bucket are written too.  Called by all threads of the workgroup (1024 or 512).
-__device__ __forceinline__ void scan_bucket_nodes(const uint32_t *cnt, uint32_t *excl, uint32_t *wave_tot, int nb, int64_t node0, int64_t N,
-                                                  unsigned long long seg_lo, uint32_t seg_n, bool publish, const RowOutputs &o)
-{
-    // two counters per thread at nb = 1024
-    const int per = (nb + (int)blockDim.x - 1) / (int)blockDim.x;
-    const int b0 = threadIdx.x * per;
-    uint32_t run = 0;
-    for (int k = 0; k < per; ++k) run += (b0 + k < nb) ? cnt[b0 + k] : 0u;
-    uint32_t inc = run;
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t x = __shfl_up(inc, off);
-        if (lane >= off) inc += x;
-    }
-    if (lane == kWave - 1) wave_tot[wv] = inc;
-    __syncthreads();
-    uint32_t pre = 0;
-    for (int w = 0; w < wv; ++w) pre += wave_tot[w];
-    uint32_t ex = pre + inc - run;
-    for (int k = 0; k < per; ++k) {
-        if (b0 + k >= nb) break;
-        const uint32_t c = cnt[b0 + k];
-        excl[b0 + k] = ex;
-        if (publish && node0 + b0 + k < N) {
-            o.rowptr[node0 + b0 + k] = (int64_t)(seg_lo + ex);
-            // (cross-workgroup appends: agent-scope atomics on the counters, plain stores into the claimed slots; nothing in
-            // THIS launch reads the lists -- the propagation launches do, and a kernel boundary orders them behind these stores)
-            if (o.hub_rows && c > (uint32_t)o.hub_threshold) {
-                if (o.mega_rows && c > (uint32_t)SS_MEGA_SLICE) {  // walked slice by slice by all hub workgroups
-                    const int slices = (int)((c + 1 + SS_MEGA_SLICE - 1) / SS_MEGA_SLICE);  // + 1: the implicit self loop
-                    const int m = atomicAdd(&o.mega_count[0], 1);
-                    const int first = atomicAdd(&o.mega_count[1], slices);
-                    reinterpret_cast<int4 *>(o.mega_rows)[m] = make_int4((int)(node0 + b0 + k), first, slices, 0);
-                } else {
-                    o.hub_rows[atomicAdd(o.hub_count, 1)] = (int32_t)(node0 + b0 + k);
-                }
-            }
-        }
-        ex += c;
-    }
-    if (threadIdx.x == 0) excl[nb] = seg_n;
-}
-
-struct FinishLds {
-    uint32_t cnt[1024], excl[1024 + 1];
-    int32_t image[kFinishCap];  // LDS image of (a node sub-range of) the bucket's col segment
-    uint32_t wave_tot[kFinishThreads / kWave];
-};
-
-// where the finish step registers the buckets it leaves to the dense launches
-struct DenseArgs {
-    int32_t *count;         // [kDenseSyncInts], see above
-    DenseBucket *list;
-    uint32_t *node_cnt;     // [dense bucket][1024]
-    uint32_t *share_off;    // [share][1024]
-    int helpers;            // helper workgroups appended to the finish launch (0: the dense steps are launches of their own)
-
-    // (workgroup-uniform, all threads) bucket blockIdx.x has seg_n > kDenseMin edges starting at col[seg_lo]
-    __device__ __forceinline__ void register_bucket(FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int nb) const
-    {
-        if (threadIdx.x == 0) {
-            const int shares = (int)((seg_n + kDensePart - 1) / kDensePart);
-            const int d = atomicAdd(&count[0], 1);
-            const int first = atomicAdd(&count[1], shares);
-            list[d] = DenseBucket{(int32_t)blockIdx.x, first, shares, seg_n, seg_lo};
-            lds.wave_tot[0] = (uint32_t)d;
-        }
-        __syncthreads();
-        uint32_t *mine = node_cnt + (size_t)lds.wave_tot[0] * 1024;
-        for (int i = threadIdx.x; i < nb; i += (int)blockDim.x) mine[i] = 0;
-        if (helpers) {  // the helpers of THIS launch read the descriptor and add to the counters: publish (G16 producer form)
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(&count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    // a bucket that is finished by its own workgroup has decided too
-    __device__ __forceinline__ void arrive() const
-    {
-        if (helpers && threadIdx.x == 0)
-            __hip_atomic_fetch_add(&count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-};
-
-template <typename Edges, typename Dense>
-__device__ __forceinline__ void finish_bucket(const Edges &edges, FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int node_shift,
-                                              int64_t N, int32_t *__restrict__ col, const RowOutputs &o, const Dense &dense)
-{
-    uint32_t *cnt = lds.cnt, *excl = lds.excl;
-    const int nb = 1 << node_shift;  // <= 1024 nodes
-    const int64_t node0 = (int64_t)blockIdx.x << node_shift;
-    if (seg_n > (uint32_t)kDenseMin) {  // (workgroup-uniform) split by edges over several workgroups: dense_count / dense_place
-        dense.register_bucket(lds, seg_lo, seg_n, nb);
-        return;
-    }
-    dense.arrive();
-    SS_TICK_START();
-    for (int i = threadIdx.x; i < nb; i += (int)blockDim.x) cnt[i] = 0;
-    __syncthreads();
-    // (workgroup-uniform) packed records of a bucket that fits the image: the counting sweep leaves them in the image array and the
-    // placing sweep takes them from there -- no second gather, no second run lookup (ppa-size finish: 9.3 us of 26.7 per workgroup)
-    const bool stashed = edges.can_stash(seg_n);
-    uint32_t *stash = reinterpret_cast<uint32_t *>(lds.image);
-    if (stashed) edges.for_each_stash(stash, [&](int, int y) { atomicAdd(&cnt[y], 1u); });
-    else edges.for_each([&](int, int y) { atomicAdd(&cnt[y], 1u); });
-    __syncthreads();
-    SS_TICK(1);
-    scan_bucket_nodes(cnt, excl, lds.wave_tot, nb, node0, N, seg_lo, seg_n, true, o);
-    __syncthreads();
-    SS_TICK(2);
-    // place the sources: node sub-ranges [n_lo, n_hi) whose edges fit the LDS image (one range when seg_n <= cap).
-    // Every sub-range re-reads the whole segment, so a bucket far above the cap (hub-heavy buckets of power-law graphs)
-    // is placed in ONE sweep straight into global memory instead: scattered 4-byte stores, but only for those buckets.
-    const bool all_direct = seg_n > 4u * (uint32_t)kFinishCap;  // (only reachable if kDenseMin is raised above 4 caps)
-    int n_lo = 0;
-    while (n_lo < nb) {
-        // largest n_hi with excl[n_hi] - excl[n_lo] <= cap; at least one node (a single node above the cap is streamed
-        // straight to global memory -- its positions are consecutive anyway).  Every thread runs the same search.
-        int lo_b = n_lo + 1, hi_b = nb;
-        while (lo_b < hi_b) {
-            const int mid = (lo_b + hi_b + 1) >> 1;
-            if (excl[mid] - excl[n_lo] <= (uint32_t)kFinishCap) lo_b = mid; else hi_b = mid - 1;
-        }
-        const int n_hi = all_direct ? nb : lo_b;
-        const uint32_t r_lo = excl[n_lo], r_n = excl[n_hi] - r_lo;
-        const bool direct = r_n > (uint32_t)kFinishCap;  // single oversized node, or the whole oversized bucket
-        for (int i = n_lo + threadIdx.x; i < n_hi; i += (int)blockDim.x) cnt[i] = excl[i] - r_lo;  // cursors relative to the range
-        __syncthreads();
-        if (r_n > 0) {
-            auto place = [&](int x, int y) {
-                if (y < n_lo || y >= n_hi) return;
-                const uint32_t pos = atomicAdd(&cnt[y], 1u);
-                if (direct) col[seg_lo + r_lo + pos] = x;
-                else lds.image[pos] = x;
-            };
-            if (stashed)  // (one range then, the whole bucket: no range check)
-                edges.replay(stash, seg_n, [&](int x, int y) { lds.image[atomicAdd(&cnt[y], 1u)] = x; });
-            else edges.for_each(place);
-            __syncthreads();
-            SS_TICK(3);
-            if (!direct)
-                for (uint32_t q = threadIdx.x; q < r_n; q += (int)blockDim.x) col[seg_lo + r_lo + q] = lds.image[q];
-        }
-        __syncthreads();
-        SS_TICK(4);
-        n_lo = n_hi;
-    }
-}
-
-// ---- single-pass plan (<= 256 fine buckets, <= kMaxTiles tiles: every shape up to ogbl-collab size) in TWO launches --------
-// tile_sort_kernel: every 4096-edge tile is sorted by bucket in LDS and written back as ONE contiguous tile (no global
-// offsets are needed for that), together with the tile's exclusive bucket offsets off[b][t] (bucket-major, so that a
-// bucket's row is contiguous).  finish_gather_kernel: the workgroup of bucket b reads rows b and b + 1 of `off`:
-//   run of tile t        = staged[t * 4096 + off[b][t] .. off[b+1][t])
-//   start of the bucket  = sum_t off[b][t]      (off[b][t] = edges of tile t with a smaller bucket: their sum over the tiles
-//                                                is the number of edges before bucket b -- no scan kernel, no global counters)
-// and then finishes the bucket like finish_kernel.  Replaces count_keys + scan_block_counts + scan_bases + scatter_tiles +
-// finish (61 us on the bench graph, three of the five launches latency-bound small grids).
-
-constexpr int kSortThreads = 512;  // 8 edges per thread (256 threads x 16 edges: 19.3 us on the collab-like graph, 512 x 8: 16.1 us)
-
+// ---- level 0: every 4096-edge tile of the caller's list is sorted by key in LDS and written back as ONE contiguous tile (no global
+// offsets are needed for that), together with the tile's exclusive key offsets off[key][tile] (key-major, so that a group's row is
+// contiguous) and the tile's max(id) + 1.  A LINK list (ss_group_links_by_source: the pairs of a query grouped by their first node):
+// src == nullptr, dst = links [B, 2] -- the key is the pair's first node, torch-style negative ids wrapped, ids out of range keyed
+// to node 0 (the query kernel itself reports them and writes their NaN rows: nothing may be dropped here), the "source" is the
+// pair's index.
+// PACKED (the only level of a one-level plan whose ids fit): records are src | (dst & (2^shift - 1)) << src_bits, 4 bytes
+template <bool PACKED>
 __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t E,
-                                                                 int64_t N, int shift, int keys, int tiles, int2 *__restrict__ staged,
+                                                                 int64_t N, int shift, int src_bits, int keys, int tiles, void *__restrict__ staged_,
                                                                  uint32_t *__restrict__ tile_off, unsigned long long *__restrict__ tile_max,
                                                                  int32_t *__restrict__ err, int32_t *__restrict__ hub_count,
                                                                  int32_t *__restrict__ mega_count, int32_t *__restrict__ dense_count,
@@ -464,7 +250,7 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
             sv[k] = src[ok[k] ? e : t0];  // (t0 < E: a valid entry for the lanes past the end)
             dv[k] = dst[ok[k] ? e : t0];
         }
-    } else {  // a link list: the key is the pair's first node, the "source" the pair's index (see fetch_edge)
+    } else {  // a link list: the key is the pair's first node, the "source" the pair's index (see above)
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int64_t e = t0 + threadIdx.x + (int64_t)k * kSortThreads;
@@ -502,13 +288,24 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
     const int lane = threadIdx.x & (kWave - 1);
     if (threadIdx.x < kMaxKeys) tile_offs[threadIdx.x] = ex;
     __syncthreads();
+    uint32_t *sorted32 = reinterpret_cast<uint32_t *>(sorted);
 #pragma unroll
     for (int k = 0; k < PER; ++k)
-        if (key[k] >= 0) sorted[tile_offs[key[k]] + rank[k]] = ed[k];
+        if (key[k] >= 0) {
+            const uint32_t pos = tile_offs[key[k]] + rank[k];
+            if (PACKED) sorted32[pos] = (uint32_t)ed[k].x | ((uint32_t)(ed[k].y & ((1 << shift) - 1)) << src_bits);
+            else sorted[pos] = ed[k];
+        }
     if ((int)threadIdx.x < keys) tile_off[(int64_t)threadIdx.x * tiles + blockIdx.x] = ex;
     if (threadIdx.x == 0) tile_off[(int64_t)keys * tiles + blockIdx.x] = tile_n;
     __syncthreads();
-    for (uint32_t q = threadIdx.x; q < tile_n; q += kSortThreads) staged[t0 + q] = sorted[q];
+    if (PACKED) {
+        uint32_t *staged = reinterpret_cast<uint32_t *>(staged_);
+        for (uint32_t q = threadIdx.x; q < tile_n; q += kSortThreads) staged[t0 + q] = sorted32[q];
+    } else {
+        int2 *staged = reinterpret_cast<int2 *>(staged_);
+        for (uint32_t q = threadIdx.x; q < tile_n; q += kSortThreads) staged[t0 + q] = sorted[q];
+    }
     unsigned long long m = my_max < 0 ? 0ULL : (unsigned long long)my_max + 1ULL;
     for (int off = kWave / 2; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_xor(m, off);
@@ -521,386 +318,7 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
     if (threadIdx.x == 0) tile_max[blockIdx.x] = block_max;
 }
 
-// ---- dense fine buckets: split by edges over several workgroups (two launches behind the finish launch) -----------------------
-struct DenseLds {
-    uint32_t cnt[1024], excl[1024 + 1];
-    uint32_t run_start[kMaxTiles + 1];  // gather plan: exclusive prefix of the bucket's run lengths over the tiles
-    uint32_t run_addr[kMaxTiles];       // gather plan: where each run starts in the tile-sorted array
-    uint32_t wave_tot[kFinishThreads / kWave];
-    int desc;
-};
-
-struct DenseShare {
-    DenseBucket b;
-    int index;         // share of its bucket
-    uint32_t lo, hi;   // flat edge range [lo, hi) of the bucket
-    int t_lo, t_hi;    // gather plan: tiles that hold it
-};
-
-// the bucket and the flat edge range of share `item` (all threads; contains barriers).  GATHER: also the run table of the bucket.
-template <bool GATHER>
-__device__ __forceinline__ DenseShare locate_share(DenseLds &lds, int item, int n_dense, const DenseBucket *__restrict__ list,
-                                                   const uint32_t *__restrict__ tile_off, int tiles)
-{
-    __syncthreads();  // the previous share's readers of lds are done
-    for (int i = threadIdx.x; i < n_dense; i += kFinishThreads) {
-        const int first = list[i].first_share;
-        if (item >= first && item < first + list[i].shares) lds.desc = i;
-    }
-    __syncthreads();
-    DenseShare sh;
-    sh.b = list[lds.desc];
-    sh.index = item - sh.b.first_share;
-    sh.lo = (uint32_t)((unsigned long long)sh.b.n * (unsigned)sh.index / (unsigned)sh.b.shares);
-    sh.hi = (uint32_t)((unsigned long long)sh.b.n * (unsigned)(sh.index + 1) / (unsigned)sh.b.shares);
-    sh.t_lo = 0;
-    sh.t_hi = 0;
-    if (GATHER) {
-        const uint32_t *row0 = tile_off + (int64_t)sh.b.bucket * tiles, *row1 = row0 + tiles;
-        // run lengths -> exclusive prefix (two tiles per thread; tiles <= kMaxTiles <= 2 * kFinishThreads)
-        const int t0 = 2 * threadIdx.x;
-        uint32_t len[2] = {0u, 0u};
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-            if (t0 + k < tiles) {
-                const uint32_t o0 = row0[t0 + k];
-                len[k] = row1[t0 + k] - o0;
-                lds.run_addr[t0 + k] = (uint32_t)(t0 + k) * (uint32_t)kTile + o0;
-            }
-        const uint32_t run = len[0] + len[1];
-        uint32_t inc = run;
-        const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t x = __shfl_up(inc, off);
-            if (lane >= off) inc += x;
-        }
-        if (lane == kWave - 1) lds.wave_tot[wv] = inc;
-        __syncthreads();
-        uint32_t pre = 0;
-        for (int w = 0; w < wv; ++w) pre += lds.wave_tot[w];
-        const uint32_t ex = pre + inc - run;
-        if (t0 < tiles) lds.run_start[t0] = ex;
-        if (t0 + 1 < tiles) lds.run_start[t0 + 1] = ex + len[0];
-        if (threadIdx.x == 0) lds.run_start[tiles] = sh.b.n;
-        __syncthreads();
-        // tiles holding [lo, hi): last tile whose start is <= lo .. last tile whose start is < hi
-        int a = 0, b = tiles;
-        while (b - a > 1) {
-            const int mid = (a + b) >> 1;
-            if (lds.run_start[mid] <= sh.lo) a = mid; else b = mid;
-        }
-        sh.t_lo = a;
-        b = tiles;
-        while (b - a > 1) {
-            const int mid = (a + b) >> 1;
-            if (lds.run_start[mid] < sh.hi) a = mid; else b = mid;
-        }
-        sh.t_hi = a;
-    }
-    return sh;
-}
-
-// f(edge) for every edge of the share, four loads in flight per thread
-template <bool GATHER, typename F>
-__device__ __forceinline__ void for_share(const DenseLds &lds, const DenseShare &sh, const int2 *__restrict__ staged, F &&f)
-{
-    for (uint32_t q0 = sh.lo; q0 < sh.hi; q0 += 4 * kFinishThreads) {
-        int2 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t q = q0 + threadIdx.x + k * kFinishThreads;
-            v[k] = make_int2(0, -1);
-            if (q < sh.hi) {
-                if (GATHER) {
-                    int a = sh.t_lo, b = sh.t_hi + 1;  // the tile whose run holds flat edge q
-                    while (b - a > 1) {
-                        const int mid = (a + b) >> 1;
-                        if (lds.run_start[mid] <= q) a = mid; else b = mid;
-                    }
-                    v[k] = staged[lds.run_addr[a] + (q - lds.run_start[a])];
-                } else {
-                    v[k] = staged[sh.b.base + q];
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (v[k].y >= 0) f(v[k]);
-    }
-}
-
-// dense_count: per-node edge counts of every share; ONE global atomic per (share, touched node), whose return value is where the
-// share's edges of that node start inside the node's row.  Shares first, first + stride, ... (all threads).
-template <bool GATHER>
-__device__ __forceinline__ void dense_count_shares(DenseLds &lds, int first, int stride, const int2 *__restrict__ staged,
-                                                   const uint32_t *__restrict__ tile_off, int tiles, int node_shift, int n_dense, int n_shares,
-                                                   const DenseBucket *__restrict__ list, uint32_t *__restrict__ node_cnt,
-                                                   uint32_t *__restrict__ share_off)
-{
-    const int nb = 1 << node_shift;
-    for (int item = first; item < n_shares; item += stride) {
-        const DenseShare sh = locate_share<GATHER>(lds, item, n_dense, list, tile_off, tiles);
-        const int node0 = sh.b.bucket << node_shift;
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = 0;
-        __syncthreads();
-        for_share<GATHER>(lds, sh, staged, [&](int2 v) { atomicAdd(&lds.cnt[v.y - node0], 1u); });
-        __syncthreads();
-        uint32_t *total = node_cnt + (size_t)lds.desc * 1024;
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads) {
-            const uint32_t c = lds.cnt[i];
-            share_off[(size_t)item * 1024 + i] = c ? atomicAdd(&total[i], c) : 0u;
-        }
-    }
-}
-
-// dense_place: row starts from the summed counters (share 0 of a bucket also publishes rowptr and the hub lists), then every edge
-// of the share goes to start + share offset + LDS cursor
-template <bool GATHER>
-__device__ __forceinline__ void dense_place_shares(DenseLds &lds, int first, int stride, const int2 *__restrict__ staged,
-                                                   const uint32_t *__restrict__ tile_off, int tiles, int node_shift, int64_t N, int n_dense,
-                                                   int n_shares, const DenseBucket *__restrict__ list, const uint32_t *__restrict__ node_cnt,
-                                                   const uint32_t *__restrict__ share_off, int32_t *__restrict__ col, const RowOutputs &o)
-{
-    const int nb = 1 << node_shift;
-    for (int item = first; item < n_shares; item += stride) {
-        const DenseShare sh = locate_share<GATHER>(lds, item, n_dense, list, tile_off, tiles);
-        const int node0 = sh.b.bucket << node_shift;
-        const uint32_t *total = node_cnt + (size_t)lds.desc * 1024;
-        // (the totals were formed by other workgroups' agent-scope atomics: read them past the L1)
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads)
-            lds.cnt[i] = __hip_atomic_load(const_cast<uint32_t *>(total) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        scan_bucket_nodes(lds.cnt, lds.excl, lds.wave_tot, nb, (int64_t)node0, N, sh.b.base, sh.b.n, sh.index == 0, o);
-        __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = lds.excl[i] + share_off[(size_t)item * 1024 + i];
-        __syncthreads();
-        for_share<GATHER>(lds, sh, staged, [&](int2 v) { col[sh.b.base + atomicAdd(&lds.cnt[v.y - node0], 1u)] = v.x; });
-    }
-}
-
-// the two steps as launches of their own (SS_CSR_DENSE=launch, and whenever the helper count cannot be established)
-template <bool GATHER>
-__global__ __launch_bounds__(kFinishThreads) void dense_count_kernel(const int2 *__restrict__ staged, const uint32_t *__restrict__ tile_off,
-                                                                     int tiles, int node_shift, const int32_t *__restrict__ dense_count,
-                                                                     const DenseBucket *__restrict__ list, uint32_t *__restrict__ node_cnt,
-                                                                     uint32_t *__restrict__ share_off, const int32_t *__restrict__ skip)
-{
-    __shared__ DenseLds lds;
-    SS_CSR_SKIP(skip);
-    dense_count_shares<GATHER>(lds, blockIdx.x, gridDim.x, staged, tile_off, tiles, node_shift, dense_count[0], dense_count[1], list, node_cnt,
-                               share_off);
-}
-
-template <bool GATHER>
-__global__ __launch_bounds__(kFinishThreads) void dense_place_kernel(const int2 *__restrict__ staged, const uint32_t *__restrict__ tile_off,
-                                                                     int tiles, int node_shift, int64_t N, const int32_t *__restrict__ dense_count,
-                                                                     const DenseBucket *__restrict__ list, const uint32_t *__restrict__ node_cnt,
-                                                                     const uint32_t *__restrict__ share_off, int32_t *__restrict__ col, RowOutputs o)
-{
-    __shared__ DenseLds lds;
-    SS_CSR_SKIP(o.skip);
-    dense_place_shares<GATHER>(lds, blockIdx.x, gridDim.x, staged, tile_off, tiles, node_shift, N, dense_count[0], dense_count[1], list,
-                               node_cnt, share_off, col, o);
-}
-
-// ---- the same two steps by HELPER workgroups of the finish launch itself (default) ------------------------------------------
-// Two launches that find nothing to do cost ~4.5 us each on an unskewed graph (2 % of a build + query step at ogbl-collab size).
-// Instead the finish launch carries `helpers` extra workgroups (blockIdx >= the number of fine buckets): a helper waits until every
-// bucket workgroup has decided (count[2], bumped right after a bucket's size is known), leaves if nothing was registered, and
-// otherwise runs the count step over its shares, meets the other helpers at a counter barrier (count[3]) and runs the place step.
-// No deadlock whatever the dispatch order: bucket workgroups never wait for anybody, and the host sizes `helpers` to at most a QUARTER (half would do for one process; two may share a GPU) of
-// the workgroups of this kernel the device can hold, so waiting helpers can never occupy every slot the bucket workgroups (or the
-// helpers still to be dispatched) need -- the host actually stays at a quarter, for processes that share a GPU.  Hand-offs follow cdna_hip_programming.md Guideline 16: producer stores -> barrier ->
-// lane-0 agent release fence -> s_waitcnt vmcnt(0) -> relaxed agent atomic; consumer relaxed poll -> agent acquire fence -> barrier.
-// wave 0 polls the sum of `words` counters `stride` ints apart until it reaches `target`; everybody leaves behind an acquire
-__device__ __forceinline__ void wait_for_count(int32_t *first, int words, int stride, int target)
-{
-    if (threadIdx.x < kWave) {
-        long spins = 0;
-        for (;;) {
-            int v = (int)threadIdx.x < words ? __hip_atomic_load(first + stride * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (v >= target) break;  // wave-uniform
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1L << 26)) __builtin_trap();  // (minutes: a launch error instead of a hang if the protocol is ever broken)
-        }
-        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
-
-template <bool GATHER>
-__device__ __forceinline__ void dense_helper(DenseLds &lds, int helper, int n_buckets, const int2 *__restrict__ staged,
-                                             const uint32_t *__restrict__ tile_off, int tiles, int node_shift, int64_t N,
-                                             int32_t *__restrict__ col, const RowOutputs &o, const DenseArgs &dense)
-{
-    wait_for_count(&dense.count[kArriveBase], kArriveWords, 16, n_buckets);
-    const int n_dense = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int n_shares = __hip_atomic_load(&dense.count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n_shares == 0) return;  // every unskewed graph
-    dense_count_shares<GATHER>(lds, helper, dense.helpers, staged, tile_off, tiles, node_shift, n_dense, n_shares, dense.list, dense.node_cnt,
-                               dense.share_off);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&dense.count[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    wait_for_count(&dense.count[3], 1, 0, dense.helpers);
-    dense_place_shares<GATHER>(lds, helper, dense.helpers, staged, tile_off, tiles, node_shift, N, n_dense, n_shares, dense.list,
-                               dense.node_cnt, dense.share_off, col, o);
-}
-
-static_assert(sizeof(DenseLds) <= sizeof(int32_t) * kFinishCap, "the helpers' LDS aliases the finish step's col image");
-
-__global__ __launch_bounds__(kFinishThreads) void finish_gather_kernel(const int2 *__restrict__ staged, const uint32_t *__restrict__ tile_off,
-                                                                       const unsigned long long *__restrict__ tile_max, int tiles, int keys,
-                                                                       int node_shift, int64_t N, int32_t *__restrict__ col,
-                                                                       unsigned long long *__restrict__ n_self, RowOutputs o, DenseArgs dense)
-{
-    __shared__ FinishLds lds;
-    __shared__ uint32_t seg[kMaxTiles];
-    __shared__ uint16_t long_tiles[kLongCap];
-    __shared__ int n_long_s;
-    __shared__ unsigned long long red_base[kFinishThreads / kWave], red_max[kFinishThreads / kWave];
-    __shared__ uint32_t red_n[kFinishThreads / kWave];
-    SS_CSR_SKIP(o.skip);
-    if ((int)blockIdx.x >= keys) {  // helper workgroup (see dense_helper)
-        dense_helper<true>(*reinterpret_cast<DenseLds *>(lds.image), (int)blockIdx.x - keys, keys, staged, tile_off, tiles, node_shift, N, col, o,
-                           dense);
-        return;
-    }
-    const uint32_t *row0 = tile_off + (int64_t)blockIdx.x * tiles, *row1 = row0 + tiles;
-    unsigned long long base = 0, mx = 0;
-    uint32_t n = 0;
-    if (threadIdx.x == 0) n_long_s = 0;
-    __syncthreads();
-    for (int t = threadIdx.x; t < tiles; t += kFinishThreads) {
-        const uint32_t o0 = row0[t], o1 = row1[t];
-        seg[t] = o0 | ((o1 - o0) << 16);
-        if (o1 - o0 > (uint32_t)kLongRun) {
-            const int k = atomicAdd(&n_long_s, 1);
-            if (k < kLongCap) long_tiles[k] = (uint16_t)t;
-        }
-        base += o0;
-        n += o1 - o0;
-        if (blockIdx.x == 0) {  // the first workgroup also reduces max(edge_index) + 1 (the self-loop count, hashing.py:148)
-            const unsigned long long v = tile_max[t];
-            mx = v > mx ? v : mx;
-        }
-    }
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-        base += __shfl_xor(base, off);
-        n += __shfl_xor(n, off);
-        const unsigned long long o = __shfl_xor(mx, off);
-        mx = o > mx ? o : mx;
-    }
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        red_base[threadIdx.x / kWave] = base;
-        red_n[threadIdx.x / kWave] = n;
-        red_max[threadIdx.x / kWave] = mx;
-    }
-    __syncthreads();
-    base = 0, n = 0, mx = 0;
-    for (int w = 0; w < kFinishThreads / kWave; ++w) {
-        base += red_base[w];
-        n += red_n[w];
-        mx = red_max[w] > mx ? red_max[w] : mx;
-    }
-    if (threadIdx.x == 0) {
-        if (blockIdx.x == 0) *n_self = mx;
-        if ((int)blockIdx.x == keys - 1) o.rowptr[N] = (int64_t)(base + n);  // the last bucket ends the edge list
-    }
-    const uint32_t avg_run = n / (uint32_t)tiles;  // workgroup-uniform
-    const int n_long = n_long_s <= kLongCap ? n_long_s : 0;  // (red_* were written behind a barrier: n_long_s is final here)
-    const int node0 = (int)((int64_t)blockIdx.x << node_shift);
-    if (avg_run < 11)
-        finish_bucket(GatheredEdges<16>{staged, seg, tiles, long_tiles, n_long, node0}, lds, base, n, node_shift, N, col, o, dense);
-    else if (avg_run < 22)
-        finish_bucket(GatheredEdges<32>{staged, seg, tiles, long_tiles, n_long, node0}, lds, base, n, node_shift, N, col, o, dense);
-    else
-        finish_bucket(GatheredEdges<64>{staged, seg, tiles, long_tiles, n_long, node0}, lds, base, n, node_shift, N, col, o, dense);
-}
-
-// ==== level plans: every graph the two-launch gather plan above does not take ==================================================
-// The gather plan generalised to 1 - 3 tile-sort LEVELS (round 4; replaces the count -> scan -> scatter partition passes: two
-// counting kernels that re-read the edges and three scans per pass, 3.6x the algorithmic traffic on ogbl-ppa / -citation2 size
-// graphs).  A level never needs global offsets: every 4096-edge tile is sorted by that level's key in LDS and written back
-// as one contiguous tile, together with the tile's exclusive key offsets off[key][tile] ("run descriptors").  The next level's
-// input for group G = (parent group g, key k) is the VIRTUAL concatenation of the runs (tile, k) over the tiles of g, read through
-// those descriptors and cut into 4096-edge chunks: chunk c of G becomes tile (G, c) of the next level.  What is needed between two
-// levels is small: per (g, k) a prefix of the run lengths over the tiles (level_scan_kernel: where does chunk c begin), the tile
-// ranges tb[G] of the groups (level_tiles_kernel) and the group of each tile (level_fill_kernel) -- descriptor-sized arrays, no
-// pass over the edges.  The finish launch gathers a fine bucket's runs from the tiles of its parent group exactly like
-// finish_gather_kernel; the start of the bucket in col is base[g] + sum over those tiles of off[k][tile].
-//   level 0   tile_sort_kernel          edges (16 B) -> tiles of (src, dst) int2, off0
-//   level l   regroup_sort_kernel       runs of level l - 1 -> tiles keyed by the next bits of dst; the LAST level writes packed
-//                                       4-byte records src | (dst & (2^node_shift - 1)) << src_bits when the ids fit
-//   finish    finish_runs_kernel        one workgroup per fine bucket; dense buckets are split over TILE ranges of about
-//                                       kDensePart edges each (runs are at most a tile long, so tile granularity balances them)
-// Traffic per edge: 16 + 8 (level 0) + 8 + 4 (level 1, packed) + 4 (+ 4 re-read, mostly from L2) + 4 (finish) = 44 - 48 B against
-// 72 B measured for the partition passes.
-constexpr int kMaxLevels = 3;
-constexpr int kRegroupThreads = 512;
-constexpr int kRunCap = 1024;        // run descriptors the finish step of a level plan keeps in LDS (two workgroups per CU: 80 KB each)
-constexpr int kRegroupRuns = 512;    // run descriptors a regroup workgroup holds at a time (more: further rounds)
-
-struct LevelPlan {
-    int levels;
-    int node_shift;
-    int shift[kMaxLevels];          // level l keys on dst >> shift[l]; shift[levels - 1] == node_shift
-    int keys[kMaxLevels];           // fan-out (level 0: ceil(N / 2^shift[0]) <= 256; below: powers of two <= 256)
-    int log2_keys[kMaxLevels];      // -1 at level 0
-    int64_t groups[kMaxLevels + 1]; // groups[l]: groups at the INPUT of level l (groups[0] = 1); groups[levels]: fine buckets
-    int64_t tmax[kMaxLevels];       // tile slots of level l (row stride of its descriptor arrays)
-    bool packed;                    // records of the last level are 4 bytes
-    int src_bits;                   // 32 - node_shift
-};
-
-inline int ceil_log2_i64(int64_t x)
-{
-    int b = 0;
-    while (((int64_t)1 << b) < x) ++b;
-    return b;
-}
-
-// node_shift / fine_buckets as make_plan chose them; max_src: sources are < max_src (N for edge lists, B for link lists)
-inline bool make_level_plan(int64_t N, int64_t E, int64_t max_src, int node_shift, LevelPlan &p)
-{
-    const int64_t n = N > 0 ? N : 1;
-    const int64_t fine = (n + ((int64_t)1 << node_shift) - 1) >> node_shift;
-    if (E >= ((int64_t)1 << 32) - 2 * kTile) return false;  // record indices are 32-bit
-    const int tb = ceil_log2_i64(fine);
-    if (tb > 24) return false;
-    p.node_shift = node_shift;
-    p.levels = fine <= kMaxKeys ? 1 : (tb <= 16 ? 2 : 3);
-    int below[kMaxLevels] = {0, 0, 0};  // key bits of the levels under level 0
-    if (p.levels == 2) below[1] = tb / 2;
-    if (p.levels == 3) { below[2] = tb / 3; below[1] = (tb - below[2]) / 2; }
-    int s = node_shift;
-    for (int l = p.levels - 1; l >= 1; --l) {
-        p.shift[l] = s;
-        p.keys[l] = 1 << below[l];
-        p.log2_keys[l] = below[l];
-        s += below[l];
-    }
-    p.shift[0] = s;
-    p.keys[0] = (int)((n + ((int64_t)1 << s) - 1) >> s);
-    p.log2_keys[0] = -1;
-    if (p.keys[0] > kMaxKeys) return false;
-    const int64_t tiles0 = (E + kTile - 1) / kTile;
-    p.groups[0] = 1;
-    p.tmax[0] = tiles0 > 0 ? tiles0 : 1;
-    for (int l = 1; l <= p.levels; ++l) {
-        p.groups[l] = (n + ((int64_t)1 << p.shift[l - 1]) - 1) >> p.shift[l - 1];
-        if (l < p.levels) p.tmax[l] = tiles0 + p.groups[l];
-    }
-    p.src_bits = 32 - node_shift;
-    p.packed = max_src <= ((int64_t)1 << p.src_bits) && !getenv("SS_CSR_NO_PACK");
-    return true;
-}
-
+// ---- levels >= 1 -------------------------------------------------------------------------------------------------------------------
 // what a regroup workgroup needs to know about its tile, in one 32-byte load (level_fill_kernel)
 struct __attribute__((aligned(32))) TileHeader {
     uint32_t group;       // G
@@ -951,7 +369,7 @@ __device__ __forceinline__ ChildGroup child_group(const ParentLevel &p, int64_t 
 }
 
 // one workgroup per group G of the NEXT level: exclusive prefix of its run lengths over the parent's tiles (prefix[k][tile]), its
-// edge count and where it starts (base of the parent group + sum over the tiles of off[k][tile], as in finish_gather_kernel)
+// edge count and where it starts (base of the parent group + sum over the tiles of off[k][tile]: off[k][tile] counts the edges of the tile with a smaller key)
 __global__ __launch_bounds__(1024) void level_scan_kernel(ParentLevel par, uint32_t *__restrict__ prefix, uint32_t *__restrict__ cfirst,
                                                           uint32_t *__restrict__ gcount, unsigned long long *__restrict__ base_next,
                                                           const int32_t *__restrict__ skip)
@@ -1090,7 +508,7 @@ struct LevelOut {
 // first run comes from a small table; the runs are <= kRegroupRuns descriptors in LDS (a chunk that spans more -- runs shorter
 // than 8 edges on average -- takes further rounds).  Then exactly tile_sort_kernel: LDS counting sort by the level's key.
 template <bool PACKED>
-__global__ __launch_bounds__(kRegroupThreads) void regroup_sort_kernel(ParentLevel par, const int2 *__restrict__ staged_in,
+__global__ __launch_bounds__(kRegroupThreads) __attribute__((amdgpu_waves_per_eu(8))) void regroup_sort_kernel(ParentLevel par, const int2 *__restrict__ staged_in,
                                                                        const uint32_t *__restrict__ prefix, LevelOut out,
                                                                        const int32_t *__restrict__ skip)
 {
@@ -1208,18 +626,105 @@ __global__ __launch_bounds__(kRegroupThreads) void regroup_sort_kernel(ParentLev
     }
 }
 
+// ---- finish: one workgroup per fine bucket --------------------------------------------------------------------------------
+struct RowOutputs {
+    int64_t *rowptr;
+    int hub_threshold;
+    int32_t *hub_rows, *hub_count, *mega_rows, *mega_count;
+    const int32_t *skip;  // see SS_CSR_SKIP
+};
+
+// exclusive scan of the per-node edge counts cnt[0..nb) of the bucket that starts at node0 -> excl[0..nb]; with `publish` the
+// row starts (rowptr) and the hub / mega rows of the bucket are written too.  Called by all threads of the workgroup.
+__device__ __forceinline__ void scan_bucket_nodes(const uint32_t *cnt, uint32_t *excl, uint32_t *wave_tot, int nb, int64_t node0, int64_t N,
+                                                  unsigned long long seg_lo, uint32_t seg_n, bool publish, const RowOutputs &o)
+{
+    // two counters per thread at nb = 1024
+    const int per = (nb + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int b0 = threadIdx.x * per;
+    uint32_t run = 0;
+    for (int k = 0; k < per; ++k) run += (b0 + k < nb) ? cnt[b0 + k] : 0u;
+    uint32_t inc = run;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t x = __shfl_up(inc, off);
+        if (lane >= off) inc += x;
+    }
+    if (lane == kWave - 1) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int w = 0; w < wv; ++w) pre += wave_tot[w];
+    uint32_t ex = pre + inc - run;
+    for (int k = 0; k < per; ++k) {
+        if (b0 + k >= nb) break;
+        const uint32_t c = cnt[b0 + k];
+        excl[b0 + k] = ex;
+        if (publish && node0 + b0 + k < N) {
+            o.rowptr[node0 + b0 + k] = (int64_t)(seg_lo + ex);
+            // (cross-workgroup appends: agent-scope atomics on the counters, plain stores into the claimed slots; nothing in
+            // THIS launch reads the lists -- the propagation launches do, and a kernel boundary orders them behind these stores)
+            if (o.hub_rows && c > (uint32_t)o.hub_threshold) {
+                if (o.mega_rows && c > (uint32_t)SS_MEGA_SLICE) {  // walked slice by slice by all hub workgroups
+                    const int slices = (int)((c + 1 + SS_MEGA_SLICE - 1) / SS_MEGA_SLICE);  // + 1: the implicit self loop
+                    const int m = atomicAdd(&o.mega_count[0], 1);
+                    const int first = atomicAdd(&o.mega_count[1], slices);
+                    reinterpret_cast<int4 *>(o.mega_rows)[m] = make_int4((int)(node0 + b0 + k), first, slices, 0);
+                } else {
+                    o.hub_rows[atomicAdd(o.hub_count, 1)] = (int32_t)(node0 + b0 + k);
+                }
+            }
+        }
+        ex += c;
+    }
+    if (threadIdx.x == 0) excl[nb] = seg_n;
+}
+
+struct FinishLds {
+    uint32_t cnt[1024], excl[1024 + 1];
+    int32_t image[kFinishCap];  // LDS image of the bucket's col segment (before: the bucket's packed records, see RunEdges::replay)
+    uint32_t wave_tot[kDenseThreads / kWave];
+};
+
+// ---- cross-workgroup waits of the dense helpers ----------------------------------------------------------------------------------
+// Two launches that find nothing to do cost ~4.5 us each on an unskewed graph (a fifth of a collab-size build).  Instead the finish
+// launch of a one-level plan carries `helpers` extra workgroups (blockIdx >= the number of fine buckets): a helper waits until every
+// bucket workgroup has decided (the sharded arrive words, bumped right after a bucket's size is known), leaves if nothing was
+// registered, and otherwise runs the count step over its shares, meets the other helpers at a counter barrier (count[3]) and runs
+// the place step.  No deadlock whatever the dispatch order: bucket workgroups never wait for anybody, and the host sizes `helpers`
+// to at most a QUARTER (half would do for one process; two may share a GPU) of the workgroups of this kernel the device can hold,
+// so waiting helpers can never occupy every slot the bucket workgroups (or the helpers still to be dispatched) need.  (Under a
+// CU mask that bound does not hold: SS_CSR_DENSE=launch selects the stand-alone launches; plans of two or three levels always
+// use them.)  Hand-offs follow cdna_hip_programming.md Guideline 16: producer stores -> barrier -> lane-0 agent release fence ->
+// s_waitcnt vmcnt(0) -> relaxed agent atomic; consumer relaxed poll -> agent acquire fence -> barrier.
+// wave 0 polls the sum of `words` counters `stride` ints apart until it reaches `target`; everybody leaves behind an acquire
+__device__ __forceinline__ void wait_for_count(int32_t *first, int words, int stride, int target)
+{
+    if (threadIdx.x < kWave) {
+        long spins = 0;
+        for (;;) {
+            int v = (int)threadIdx.x < words ? __hip_atomic_load(first + stride * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (v >= target) break;  // wave-uniform
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1L << 26)) __builtin_trap();  // (minutes: a launch error instead of a hang if the protocol is ever broken)
+        }
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
 // ---- finish over runs ------------------------------------------------------------------------------------------------------------
-constexpr int kRunThreads = 512;     // finish_runs_kernel: two workgroups per CU at 128 VGPRs, positions in steps of 512 (less padding than 1024)
-constexpr int kRunBlocks = (kDenseMin + kTile) / kWave;  // 64-position blocks of the largest bucket a workgroup walks itself
+constexpr int kRunBlocks = (kDenseMin + kTile) / kWave;  // 64-position blocks of the largest bucket / share a workgroup walks
 struct RunLds {
     uint32_t delta[kRunCap];           // first record of the run of each listed tile MINUS the run's first position: record = delta + position
     uint16_t start[kRunCap + 4];       // exclusive prefix of the run lengths: position of each run's first edge; [n] = total, then 0xFFFF
     uint16_t first_run[kRunBlocks + 2];  // the run that holds the first position of each 64-position block
-    uint32_t wave_tot[kFinishThreads / kWave];
+    uint32_t wave_tot[kDenseThreads / kWave];
 };
-static_assert(kDenseMin + kTile < 65536 && kDensePart + kTile < kDenseMin, "16-bit positions");
+static_assert(kDenseMin + kTile < 65536 && kDensePart <= kDenseMin, "16-bit positions");
 
-// The runs (tile, k) of the tiles [t_lo, t_hi) as an edge source for finish_bucket / the dense steps, walked by POSITION: the edges
+// The runs (tile, k) of the tiles [t_lo, t_hi) as an edge source for the finish step and the dense steps, walked by POSITION: the edges
 // of the listed runs are numbered 0 .. total in tile order and thread i takes positions i, i + THREADS, ...: every lane has an edge
 // whatever the run lengths are (16 lanes per 18-edge run left a quarter of them idle and a second dependent load for every run
 // above the lane group: 271 us for the ppa-size finish), a wavefront's 64 positions are consecutive records of one or two runs, and
@@ -1365,8 +870,6 @@ struct RunEdges {
         for (; p0 + 2 * THREADS <= total; p0 += 2 * THREADS) batch<2, true, STASH>(p0, total, stash, f);
         if (p0 < total) batch<2, false, STASH>(p0, total, stash, f);
     }
-    // can the first for_each leave the records in a kFinishCap-word LDS array for the second one?
-    __device__ __forceinline__ bool can_stash(uint32_t total) const { return PACKED && resident() && total <= (uint32_t)kFinishCap; }
     template <typename F>
     __device__ __forceinline__ void for_each_stash(uint32_t *stash, F &&f) const { walk<true>(lds->start[t_hi - t_lo], stash, f); }
     // the stashed records again; f may overwrite the stash array (every thread holds its records in registers behind a barrier)
@@ -1419,6 +922,7 @@ struct DenseRunBucket {
 };
 
 struct DenseRunArgs {
+    static constexpr int kMin = kDenseMin;
     int32_t *count;           // [0] dense buckets, [1] shares
     DenseRunBucket *list;
     uint32_t *node_cnt;       // [dense bucket][1024]
@@ -1426,6 +930,7 @@ struct DenseRunArgs {
     uint32_t *share_lo;       // [share] first tile of each share
     const uint32_t *row0, *row1;  // descriptor rows of the registering bucket (set per workgroup)
     int t_lo, t_hi;
+    int helpers;              // helper workgroups appended to the finish launch (0: the dense steps are launches of their own)
 
     // the bucket's runs in tile order: a share ends behind the tile in which the running edge count crosses a multiple of kDensePart
     __device__ __forceinline__ void register_bucket(FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int nb) const
@@ -1467,9 +972,148 @@ struct DenseRunArgs {
             if (s_hi != s_lo && s_hi < (uint32_t)shares) share_lo[first + s_hi] = (uint32_t)(t + 1);  // (a run is at most a tile: one crossing)
             carry += tot;
         }
+        if (helpers) {  // the helpers of THIS launch read the descriptor, the share bounds and the zeroed counters: publish (G16 producer form)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
-    __device__ __forceinline__ void arrive() const {}
+    // a bucket that is finished by its own workgroup has decided too
+    __device__ __forceinline__ void arrive() const
+    {
+        if (helpers && threadIdx.x == 0)
+            __hip_atomic_fetch_add(&count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 };
+
+// the two dense steps of a level plan: launches of their own (they exit at once when nothing was registered), or run by helper
+// workgroups of the finish launch (one-level plans, where two empty launches are a fifth of the build)
+struct DenseRunLds {
+    uint32_t cnt[1024], excl[1024 + 1];
+    uint32_t wave_tot[kDenseThreads / kWave];
+    RunLds runs;
+    int desc;
+};
+static_assert(sizeof(DenseRunLds) <= sizeof(int32_t) * kFinishCap, "the helpers' LDS aliases the finish step's col image");
+
+struct DenseRunWork {  // what the dense steps read
+    ParentLevel par;
+    const void *staged;
+    int node_shift, src_bits;
+    int64_t N;
+    const DenseRunBucket *list;
+    const uint32_t *share_lo;
+    uint32_t *node_cnt, *share_off;
+    int32_t *col;
+};
+
+// (all threads; barriers) the bucket of share `item` and its tile range; the descriptors of the range (or of its first batch) -> LDS
+template <bool PACKED, int THREADS>
+__device__ __forceinline__ RunEdges<PACKED, THREADS> locate_run_share(DenseRunLds &lds, int item, int n_dense, const DenseRunWork &w, DenseRunBucket &b)
+{
+    __syncthreads();  // the previous share's readers of lds are done
+    for (int i = threadIdx.x; i < n_dense; i += THREADS) {
+        const int first = w.list[i].first_share;
+        if (item >= first && item < first + w.list[i].shares) lds.desc = i;
+    }
+    __syncthreads();
+    b = w.list[lds.desc];
+    const int s = item - b.first_share;
+    const int t_lo = (int)w.share_lo[item], t_hi = s + 1 < b.shares ? (int)w.share_lo[item + 1] : b.t_hi;
+    const ChildGroup c = child_group(w.par, b.bucket);
+    const uint32_t *row0 = w.par.off + (int64_t)c.k * w.par.tmax, *row1 = row0 + w.par.tmax;
+    RunEdges<PACKED, THREADS> e{w.staged, row0, row1, w.par.tstart, t_lo, t_hi, &lds.runs, w.src_bits, (int)((int64_t)b.bucket << w.node_shift)};
+    if (e.resident()) e.prepare(t_lo, t_hi - t_lo);
+    return e;
+}
+
+// per-node edge counts of every share; ONE global atomic per (share, touched node), whose return value is where the share's edges
+// of that node start inside the node's row.  Shares first, first + stride, ... (all threads)
+template <bool PACKED, int THREADS>
+__device__ __forceinline__ void dense_count_run_shares(DenseRunLds &lds, int first, int stride, int n_dense, int n_shares, const DenseRunWork &w)
+{
+    const int nb = 1 << w.node_shift;
+    for (int item = first; item < n_shares; item += stride) {
+        DenseRunBucket b;
+        const RunEdges<PACKED, THREADS> edges = locate_run_share<PACKED, THREADS>(lds, item, n_dense, w, b);
+        for (int i = threadIdx.x; i < nb; i += THREADS) lds.cnt[i] = 0;
+        __syncthreads();
+        edges.for_each([&](int, int y) { atomicAdd(&lds.cnt[y], 1u); });
+        __syncthreads();
+        uint32_t *total = w.node_cnt + (size_t)lds.desc * 1024;
+        for (int i = threadIdx.x; i < nb; i += THREADS) {
+            const uint32_t c = lds.cnt[i];
+            w.share_off[(size_t)item * 1024 + i] = c ? atomicAdd(&total[i], c) : 0u;
+        }
+    }
+}
+
+// row starts from the summed counters (the first share of a bucket also publishes rowptr and the hub lists), then every edge of the
+// share goes to start + share offset + LDS cursor
+template <bool PACKED, int THREADS>
+__device__ __forceinline__ void dense_place_run_shares(DenseRunLds &lds, int first, int stride, int n_dense, int n_shares, const DenseRunWork &w,
+                                                       const RowOutputs &o)
+{
+    const int nb = 1 << w.node_shift;
+    for (int item = first; item < n_shares; item += stride) {
+        DenseRunBucket b;
+        const RunEdges<PACKED, THREADS> edges = locate_run_share<PACKED, THREADS>(lds, item, n_dense, w, b);
+        const uint32_t *total = w.node_cnt + (size_t)lds.desc * 1024;
+        // (the totals were formed by other workgroups' agent-scope atomics, possibly in this launch: read them past the L1)
+        for (int i = threadIdx.x; i < nb; i += THREADS)
+            lds.cnt[i] = __hip_atomic_load(const_cast<uint32_t *>(total) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        scan_bucket_nodes(lds.cnt, lds.excl, lds.wave_tot, nb, (int64_t)b.bucket << w.node_shift, w.N, b.base, b.n, item == b.first_share, o);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += THREADS) lds.cnt[i] = lds.excl[i] + w.share_off[(size_t)item * 1024 + i];
+        __syncthreads();
+        const unsigned long long cbase = b.base;
+        int32_t *col = w.col;
+        edges.for_each([&](int x, int y) { col[cbase + atomicAdd(&lds.cnt[y], 1u)] = x; });
+    }
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(kDenseThreads) void dense_count_runs_kernel(DenseRunWork w, const int32_t *__restrict__ dense_count,
+                                                                          const int32_t *__restrict__ skip)
+{
+    __shared__ DenseRunLds lds;
+    SS_CSR_SKIP(skip);
+    dense_count_run_shares<PACKED, kDenseThreads>(lds, blockIdx.x, gridDim.x, dense_count[0], dense_count[1], w);
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(kDenseThreads) void dense_place_runs_kernel(DenseRunWork w, const int32_t *__restrict__ dense_count, RowOutputs o)
+{
+    __shared__ DenseRunLds lds;
+    SS_CSR_SKIP(o.skip);
+    dense_place_run_shares<PACKED, kDenseThreads>(lds, blockIdx.x, gridDim.x, dense_count[0], dense_count[1], w, o);
+}
+
+// helper workgroups of the finish launch (blockIdx >= the number of fine buckets; see dense_helper above for the protocol and why
+// the bound on their number excludes a deadlock): wait until every bucket workgroup has decided, leave if nothing was registered,
+// otherwise count, meet the other helpers at a counter barrier, place
+template <bool PACKED>
+__device__ __forceinline__ void dense_run_helper(DenseRunLds &lds, int helper, int n_buckets, const DenseRunWork &w, const RowOutputs &o,
+                                                 const DenseRunArgs &dense)
+{
+    wait_for_count(&dense.count[kArriveBase], kArriveWords, 16, n_buckets);
+    const int n_dense = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n_shares = __hip_atomic_load(&dense.count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n_shares == 0) return;  // every unskewed graph
+    dense_count_run_shares<PACKED, kRunThreads>(lds, helper, dense.helpers, n_dense, n_shares, w);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&dense.count[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    wait_for_count(&dense.count[3], 1, 0, dense.helpers);
+    dense_place_run_shares<PACKED, kRunThreads>(lds, helper, dense.helpers, n_dense, n_shares, w, o);
+}
 
 template <bool PACKED>
 __global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel par, const void *__restrict__ staged,
@@ -1483,6 +1127,11 @@ __global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel pa
     __shared__ unsigned long long red_base[kRunThreads / kWave], red_max[kRunThreads / kWave];
     __shared__ uint32_t red_n[kRunThreads / kWave];
     SS_CSR_SKIP(o.skip);
+    if ((int64_t)blockIdx.x >= fine_buckets) {  // helper workgroup
+        const DenseRunWork w = {par, staged, node_shift, src_bits, N, dense.list, dense.share_lo, dense.node_cnt, dense.share_off, col};
+        dense_run_helper<PACKED>(*reinterpret_cast<DenseRunLds *>(lds.image), (int)(blockIdx.x - fine_buckets), (int)fine_buckets, w, o, dense);
+        return;
+    }
     SS_TICK_START();
     const ChildGroup c = child_group(par, blockIdx.x);
     const uint32_t *row0 = par.off + (int64_t)c.k * par.tmax, *row1 = row0 + par.tmax;
@@ -1533,107 +1182,52 @@ __global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel pa
     dense.t_lo = c.t_lo;
     dense.t_hi = c.t_hi;
     SS_TICK(0);
-    finish_bucket(edges, lds, base, n, node_shift, N, col, o, dense);
-}
-
-// the two dense steps of a level plan (launches of their own: they exit at once when nothing was registered)
-struct DenseRunLds {
-    uint32_t cnt[1024], excl[1024 + 1];
-    uint32_t wave_tot[kFinishThreads / kWave];
-    RunLds runs;
-    int desc;
-};
-
-// (all threads; barriers) the bucket of share `item` and its tile range; the descriptors of the range (or of its first batch) -> LDS
-template <bool PACKED>
-__device__ __forceinline__ RunEdges<PACKED, kFinishThreads> locate_run_share(DenseRunLds &lds, int item, int n_dense, const DenseRunBucket *__restrict__ list,
-                                                                 const uint32_t *__restrict__ share_lo, const ParentLevel &par,
-                                                                 const void *__restrict__ staged, int node_shift, int src_bits, DenseRunBucket &b)
-{
-    __syncthreads();  // the previous share's readers of lds are done
-    for (int i = threadIdx.x; i < n_dense; i += kFinishThreads) {
-        const int first = list[i].first_share;
-        if (item >= first && item < first + list[i].shares) lds.desc = i;
+    const int nb = 1 << node_shift;  // <= 1024 nodes
+    if (n > (uint32_t)kDenseMin) {  // (workgroup-uniform) does not fit the image: split over several workgroups by the dense steps
+        dense.register_bucket(lds, base, n, nb);
+        return;
     }
+    dense.arrive();
+    uint32_t *cnt = lds.cnt;
+    for (int i = threadIdx.x; i < nb; i += kRunThreads) cnt[i] = 0;
     __syncthreads();
-    b = list[lds.desc];
-    const int s = item - b.first_share;
-    const int t_lo = (int)share_lo[item], t_hi = s + 1 < b.shares ? (int)share_lo[item + 1] : b.t_hi;
-    const ChildGroup c = child_group(par, b.bucket);
-    const uint32_t *row0 = par.off + (int64_t)c.k * par.tmax, *row1 = row0 + par.tmax;
-    RunEdges<PACKED, kFinishThreads> e{staged, row0, row1, par.tstart, t_lo, t_hi, &lds.runs, src_bits, (int)((int64_t)b.bucket << node_shift)};
-    if (e.resident()) e.prepare(t_lo, t_hi - t_lo);
-    return e;
+    // (workgroup-uniform) packed records: the counting sweep leaves them in the image array and the placing sweep takes them from
+    // there -- no second gather, no second run lookup (ppa-size finish: 9.3 us of 26.7 per workgroup)
+    const bool stashed = PACKED && edges.resident();
+    uint32_t *stash = reinterpret_cast<uint32_t *>(lds.image);
+    if (stashed) edges.for_each_stash(stash, [&](int, int y) { atomicAdd(&cnt[y], 1u); });
+    else edges.for_each([&](int, int y) { atomicAdd(&cnt[y], 1u); });
+    __syncthreads();
+    SS_TICK(1);
+    scan_bucket_nodes(cnt, lds.excl, lds.wave_tot, nb, (int64_t)node0, N, base, n, true, o);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += kRunThreads) cnt[i] = lds.excl[i];  // cursors
+    __syncthreads();
+    SS_TICK(2);
+    auto place = [&](int x, int y) { lds.image[atomicAdd(&cnt[y], 1u)] = x; };
+    if (stashed) edges.replay(stash, n, place);
+    else edges.for_each(place);
+    __syncthreads();
+    SS_TICK(3);
+    for (uint32_t q = threadIdx.x; q < n; q += kRunThreads) col[base + q] = lds.image[q];
+    SS_TICK(4);
 }
 
-template <bool PACKED>
-__global__ __launch_bounds__(kFinishThreads) void dense_count_runs_kernel(ParentLevel par, const void *__restrict__ staged, int node_shift,
-                                                                          int src_bits, const int32_t *__restrict__ dense_count,
-                                                                          const DenseRunBucket *__restrict__ list,
-                                                                          const uint32_t *__restrict__ share_lo, uint32_t *__restrict__ node_cnt,
-                                                                          uint32_t *__restrict__ share_off, const int32_t *__restrict__ skip)
-{
-    __shared__ DenseRunLds lds;
-    SS_CSR_SKIP(skip);
-    const int n_dense = dense_count[0], n_shares = dense_count[1], nb = 1 << node_shift;
-    for (int item = blockIdx.x; item < n_shares; item += gridDim.x) {
-        DenseRunBucket b;
-        const RunEdges<PACKED, kFinishThreads> edges = locate_run_share<PACKED>(lds, item, n_dense, list, share_lo, par, staged, node_shift, src_bits, b);
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = 0;
-        __syncthreads();
-        edges.for_each([&](int, int y) { atomicAdd(&lds.cnt[y], 1u); });
-        __syncthreads();
-        uint32_t *total = node_cnt + (size_t)lds.desc * 1024;
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads) {
-            const uint32_t c = lds.cnt[i];
-            share_off[(size_t)item * 1024 + i] = c ? atomicAdd(&total[i], c) : 0u;
-        }
-    }
-}
-
-template <bool PACKED>
-__global__ __launch_bounds__(kFinishThreads) void dense_place_runs_kernel(ParentLevel par, const void *__restrict__ staged, int node_shift,
-                                                                          int src_bits, int64_t N, const int32_t *__restrict__ dense_count,
-                                                                          const DenseRunBucket *__restrict__ list,
-                                                                          const uint32_t *__restrict__ share_lo,
-                                                                          const uint32_t *__restrict__ node_cnt,
-                                                                          const uint32_t *__restrict__ share_off, int32_t *__restrict__ col,
-                                                                          RowOutputs o)
-{
-    __shared__ DenseRunLds lds;
-    SS_CSR_SKIP(o.skip);
-    const int n_dense = dense_count[0], n_shares = dense_count[1], nb = 1 << node_shift;
-    for (int item = blockIdx.x; item < n_shares; item += gridDim.x) {
-        DenseRunBucket b;
-        const RunEdges<PACKED, kFinishThreads> edges = locate_run_share<PACKED>(lds, item, n_dense, list, share_lo, par, staged, node_shift, src_bits, b);
-        const uint32_t *total = node_cnt + (size_t)lds.desc * 1024;
-        // (the totals were formed by other workgroups' agent-scope atomics in the launch before)
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = total[i];
-        __syncthreads();
-        scan_bucket_nodes(lds.cnt, lds.excl, lds.wave_tot, nb, (int64_t)b.bucket << node_shift, N, b.base, b.n, item == b.first_share, o);
-        __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += kFinishThreads) lds.cnt[i] = lds.excl[i] + share_off[(size_t)item * 1024 + i];
-        __syncthreads();
-        const unsigned long long cbase = b.base;
-        edges.for_each([&](int x, int y) { col[cbase + atomicAdd(&lds.cnt[y], 1u)] = x; });
-    }
-}
-
-struct LevelWorkspace {
+struct Workspace {
     LevelArrays lv[kMaxLevels];
     int2 *staged_a;                 // level 0 (tile j at j * kTile) and level 2
     void *staged_b;                 // level 1
     unsigned long long *tile_max;   // [tiles0]
     unsigned long long *scratch;    // [1] n_self when the caller does not want it
-    int32_t *dense_count;           // [kDenseSyncInts] (only [0], [1] are used by the level plans)
+    int32_t *dense_count;           // [kDenseSyncInts]
     DenseRunBucket *dense_list;
     uint32_t *dense_node_cnt, *dense_share_off, *dense_share_lo;
     size_t bytes;
 };
 
-inline LevelWorkspace carve_levels(const LevelPlan &p, int64_t E, void *base)
+inline Workspace carve(const LevelPlan &p, int64_t E, void *base)
 {
-    LevelWorkspace w;
+    Workspace w;
     char *c = reinterpret_cast<char *>(base);
     size_t off = 0;
     auto take = [&](size_t n) { char *r = c ? c + off : nullptr; off += align256(n); return r; };
@@ -1655,17 +1249,14 @@ inline LevelWorkspace carve_levels(const LevelPlan &p, int64_t E, void *base)
     w.tile_max = reinterpret_cast<unsigned long long *>(take((size_t)p.tmax[0] * 8));
     w.scratch = reinterpret_cast<unsigned long long *>(take(8));
     w.dense_count = reinterpret_cast<int32_t *>(take(4 * kDenseSyncInts));
-    w.dense_list = reinterpret_cast<DenseRunBucket *>(take((size_t)max_dense_buckets(E) * sizeof(DenseRunBucket)));
-    w.dense_node_cnt = reinterpret_cast<uint32_t *>(take((size_t)max_dense_buckets(E) * 1024 * 4));
-    w.dense_share_off = reinterpret_cast<uint32_t *>(take((size_t)max_dense_shares(E) * 1024 * 4));
-    w.dense_share_lo = reinterpret_cast<uint32_t *>(take((size_t)(max_dense_shares(E) + 1) * 4));
+    const int64_t db = max_dense_buckets(E), ds = max_dense_shares(E);
+    w.dense_list = reinterpret_cast<DenseRunBucket *>(take((size_t)db * sizeof(DenseRunBucket)));
+    w.dense_node_cnt = reinterpret_cast<uint32_t *>(take((size_t)db * 1024 * 4));
+    w.dense_share_off = reinterpret_cast<uint32_t *>(take((size_t)ds * 1024 * 4));
+    w.dense_share_lo = reinterpret_cast<uint32_t *>(take((size_t)(ds + 1) * 4));
     w.bytes = off;
     return w;
 }
-
-}  // namespace ss
-
-namespace ss {
 
 // ---- content fingerprint of an edge list (ss_csr_build_cached) ---------------------------------------------------------------
 // ELPH.forward concatenates a fresh self-looped edge_index every training step (reference models/elph.py:186) -- the same
@@ -1769,7 +1360,7 @@ __global__ __launch_bounds__(kFpBlocks) void fingerprint_decide_kernel(Fingerpri
 }
 
 // helper workgroups a finish launch may carry: at most a QUARTER of the workgroups of that kernel the device can hold at once
-// (see dense_helper for why such a bound excludes a deadlock), at most kDenseHelpers; 0 = use the stand-alone dense launches
+// (see dense_run_helper for why such a bound excludes a deadlock), at most kDenseHelpers; 0 = use the stand-alone dense launches
 constexpr int kDenseHelpers = 128;  // (32 .. 256 helpers finish a rank^-0.9 collab-size graph in the same time: shares outnumber none of them)
 template <typename Kernel>
 int helper_budget(Kernel kernel)
@@ -1777,7 +1368,7 @@ int helper_budget(Kernel kernel)
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kFinishThreads, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kRunThreads, 0) != hipSuccess) return 0;
     const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
     static const int cap_env = getenv("SS_CSR_HELPERS") ? atoi(getenv("SS_CSR_HELPERS")) : 0;  // tuning hook (never above the safe bound)
     const int64_t cap = cap_env > 0 && cap_env < kDenseHelpers ? cap_env : kDenseHelpers;
@@ -1785,19 +1376,19 @@ int helper_budget(Kernel kernel)
     return (int)(h > 0 ? h : 0);
 }
 
-inline int dense_helpers()
+inline int run_helpers(bool packed)
 {
     static const bool launches = getenv("SS_CSR_DENSE") && !strcmp(getenv("SS_CSR_DENSE"), "launch");
     // per device: a process may drive GPUs of different sizes.  0 = not computed yet (a device whose budget IS 0 recomputes it
     // every call: that path is the stand-alone launches and not performance critical); relaxed atomics: callers on several
     // host threads may race to fill an entry, with the same value
-    static std::atomic<int> cache[64];
+    static std::atomic<int> cache[2][64];
     int dev = 0;
     if (launches || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    int h = cache[dev].load(std::memory_order_relaxed);
+    int h = cache[packed][dev].load(std::memory_order_relaxed);
     if (h == 0) {
-        h = helper_budget(finish_gather_kernel);
-        cache[dev].store(h, std::memory_order_relaxed);
+        h = packed ? helper_budget(finish_runs_kernel<true>) : helper_budget(finish_runs_kernel<false>);
+        cache[packed][dev].store(h, std::memory_order_relaxed);
     }
     return h;
 }
@@ -1818,28 +1409,55 @@ extern "C" int ss_csr_timing_read(unsigned long long *out16, int reset)
 
 extern "C" size_t ss_csr_workspace_bytes(int64_t N, int64_t E)
 {
-    ss::CsrPlan p;
-    if (!ss::make_plan(N, E, p)) return 0;
-    if (p.gather) return ss::carve(p, E, nullptr).bytes;
     ss::LevelPlan lp;
-    if (!ss::make_level_plan(N, E, N, p.node_shift, lp)) return 0;
-    return ss::carve_levels(lp, E, nullptr).bytes;
+    if (!ss::make_plan(N, E, N, lp)) return 0;
+    return ss::carve(lp, E, nullptr).bytes;
 }
 
-static int csr_build_levels(const ss::LevelPlan &lp, const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int32_t *col,
-                            unsigned long long *n_self_or_null, const ss::RowOutputs &rows_out, int32_t *hub_count, int32_t *mega_count,
-                            int32_t *err_flag, void *workspace, hipStream_t stream, const int32_t *skip, int32_t *bad_record)
+// every check that can fail without a launch: arguments, plan, workspace (shared by the plain and the cached entry point -- the
+// cached one must not let its fingerprint kernels declare the outputs valid for a call that then builds nothing)
+static int csr_check(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, const int64_t *rowptr, const int32_t *col,
+                     const int32_t *hub_rows, const int32_t *hub_count, const int32_t *mega_rows, const int32_t *mega_count,
+                     const void *workspace, size_t workspace_bytes, ss::LevelPlan &lp)
+{
+    if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || !rowptr) return SS_ERR_INVALID_ARG;
+    if (E > 0 && (!dst || !col)) return SS_ERR_INVALID_ARG;
+    if ((hub_rows == nullptr) != (hub_count == nullptr)) return SS_ERR_INVALID_ARG;
+    if ((mega_rows == nullptr) != (mega_count == nullptr) || (mega_rows && !hub_rows)) return SS_ERR_INVALID_ARG;
+    if (!ss::make_plan(N, E, src ? N : E, lp)) return SS_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < ss_csr_workspace_bytes(N, E)) return SS_ERR_WORKSPACE;
+    return SS_OK;
+}
+
+// the launches of one build (arguments checked by csr_check)
+static int csr_build_launch(const ss::LevelPlan &lp, const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
+                            int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count, int32_t *mega_rows,
+                            int32_t *mega_count, int32_t *err_flag, void *workspace, hipStream_t stream, const int32_t *skip = nullptr,
+                            int32_t *bad_record = nullptr)
 {
     using namespace ss;
-    const LevelWorkspace w = carve_levels(lp, E, workspace);
-    unsigned long long *n_self = n_self_or_null ? n_self_or_null : w.scratch;
+    if (N == 0 || E == 0) {
+        if (n_self_loops_out && hipMemsetAsync(n_self_loops_out, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
+        if (hub_count && hipMemsetAsync(hub_count, 0, 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
+        if (mega_count && hipMemsetAsync(mega_count, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
+        if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
+        return SS_OK;
+    }
+    ProfileSpan span(stream, SS_PROF_CSR);  // all launches of this build
+    const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count, skip};
+    const Workspace w = carve(lp, E, workspace);
+    unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
     const int tiles0 = (int)lp.tmax[0];
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles0), dim3(kSortThreads), 0, stream, src, dst, E, N, lp.shift[0], lp.keys[0], tiles0, w.staged_a,
-                       w.lv[0].off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip, bad_record);
+    const bool packed = lp.packed;  // records of the last level (read by the finish step) are 4 bytes
+    if (packed && lp.levels == 1)
+        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(tiles0), dim3(kSortThreads), 0, stream, src, dst, E, N, lp.shift[0], lp.src_bits, lp.keys[0],
+                           tiles0, (void *)w.staged_a, w.lv[0].off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip, bad_record);
+    else
+        hipLaunchKernelGGL(tile_sort_kernel<false>, dim3(tiles0), dim3(kSortThreads), 0, stream, src, dst, E, N, lp.shift[0], lp.src_bits, lp.keys[0],
+                           tiles0, (void *)w.staged_a, w.lv[0].off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip, bad_record);
     SS_LAUNCH_CHECK();
     ParentLevel par = {w.lv[0].off, nullptr, nullptr, nullptr, tiles0, tiles0, lp.keys[0], -1};
     const void *in = w.staged_a;
-    const bool packed = lp.packed && lp.levels >= 2;
     for (int l = 1; l < lp.levels; ++l) {
         const LevelArrays &a = w.lv[l];
         hipLaunchKernelGGL(level_scan_kernel, dim3((unsigned)lp.groups[l]), dim3(1024), 0, stream, par, w.lv[l - 1].prefix, w.lv[l - 1].cfirst,
@@ -1865,38 +1483,36 @@ static int csr_build_levels(const ss::LevelPlan &lp, const int64_t *src, const i
         in = out_buf;
     }
     const int64_t fine = lp.groups[lp.levels];
-    const DenseRunArgs dense = {w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, w.dense_share_lo, nullptr, nullptr, 0, 0};
+    // the dense steps loop over the registered shares: no more workgroups than shares can exist
     const int64_t share_cap = max_dense_shares(E);
     const unsigned dense_grid = (unsigned)(share_cap < kDenseGrid ? share_cap : kDenseGrid);
+    // one-level plans (collab size and below: tens of microseconds per build) run the dense steps by helper workgroups of the finish
+    // launch; larger builds by two launches of their own (~9 us of a build of hundreds when they find nothing to do)
+    int helpers = lp.levels == 1 ? run_helpers(packed) : 0;
+    if ((int64_t)helpers > share_cap) helpers = (int)share_cap;
+    const DenseRunArgs dense = {w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, w.dense_share_lo, nullptr, nullptr, 0, 0, helpers};
+    const DenseRunWork work = {par, in, lp.node_shift, lp.src_bits, N, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, col};
     if (packed) {
-        hipLaunchKernelGGL(finish_runs_kernel<true>, dim3((unsigned)fine), dim3(kRunThreads), 0, stream, par, in, w.tile_max, tiles0,
+        hipLaunchKernelGGL(finish_runs_kernel<true>, dim3((unsigned)(fine + helpers)), dim3(kRunThreads), 0, stream, par, in, w.tile_max, tiles0,
                            lp.node_shift, lp.src_bits, N, col, n_self, rows_out, dense, fine);
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(dense_count_runs_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, par, in, lp.node_shift, lp.src_bits,
-                           w.dense_count, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, skip);
+        if (helpers) return SS_OK;
+        hipLaunchKernelGGL(dense_count_runs_kernel<true>, dim3(dense_grid), dim3(kDenseThreads), 0, stream, work, w.dense_count, skip);
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(dense_place_runs_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, par, in, lp.node_shift, lp.src_bits, N,
-                           w.dense_count, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, col, rows_out);
+        hipLaunchKernelGGL(dense_place_runs_kernel<true>, dim3(dense_grid), dim3(kDenseThreads), 0, stream, work, w.dense_count, rows_out);
         SS_LAUNCH_CHECK();
     } else {
-        hipLaunchKernelGGL(finish_runs_kernel<false>, dim3((unsigned)fine), dim3(kRunThreads), 0, stream, par, in, w.tile_max, tiles0,
+        hipLaunchKernelGGL(finish_runs_kernel<false>, dim3((unsigned)(fine + helpers)), dim3(kRunThreads), 0, stream, par, in, w.tile_max, tiles0,
                            lp.node_shift, lp.src_bits, N, col, n_self, rows_out, dense, fine);
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(dense_count_runs_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, par, in, lp.node_shift, lp.src_bits,
-                           w.dense_count, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, skip);
+        if (helpers) return SS_OK;
+        hipLaunchKernelGGL(dense_count_runs_kernel<false>, dim3(dense_grid), dim3(kDenseThreads), 0, stream, work, w.dense_count, skip);
         SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(dense_place_runs_kernel<false>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, par, in, lp.node_shift, lp.src_bits, N,
-                           w.dense_count, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, col, rows_out);
+        hipLaunchKernelGGL(dense_place_runs_kernel<false>, dim3(dense_grid), dim3(kDenseThreads), 0, stream, work, w.dense_count, rows_out);
         SS_LAUNCH_CHECK();
     }
     return SS_OK;
 }
-
-static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
-                          int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
-                          int32_t *mega_rows, int32_t *mega_count,
-                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *skip = nullptr,
-                          int32_t *bad_record = nullptr);
 
 extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                             int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
@@ -1904,8 +1520,11 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
                             int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_)
 {
     if (E > 0 && !src) return SS_ERR_INVALID_ARG;
-    return csr_build_impl(src, dst, E, N, rowptr, col, n_self_loops_out, hub_threshold, hub_rows, hub_count, mega_rows, mega_count, err_flag,
-                          workspace, workspace_bytes, stream_);
+    ss::LevelPlan lp;
+    const int rc = csr_check(src, dst, E, N, rowptr, col, hub_rows, hub_count, mega_rows, mega_count, workspace, workspace_bytes, lp);
+    if (rc != SS_OK) return rc;
+    return csr_build_launch(lp, src, dst, E, N, rowptr, col, n_self_loops_out, hub_threshold, hub_rows, hub_count, mega_rows, mega_count, err_flag,
+                            workspace, (hipStream_t)stream_);
 }
 
 // ss_csr_build that first compares a content fingerprint of (src, dst) with the one the previous call left in `fingerprint`
@@ -1913,6 +1532,9 @@ extern "C" int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, i
 // the outputs already hold this CSR and every kernel of the build exits at once; different (or first use) -> an ordinary build,
 // after which `fingerprint` describes the new contents.  No host synchronisation either way.  A skipped call re-reports (err_flag)
 // the out-of-range ids the build of the cached CSR met.  (reference models/elph.py:186 + runners/train.py:188-198: the same edges in a fresh tensor every step)
+// Every check that can fail without a launch runs BEFORE the fingerprint kernels (they declare the outputs valid for this edge
+// list); if a launch of the build itself fails after them, the fingerprint is invalidated on the stream before the error is
+// returned -- a later call with the same edges must not skip over a CSR that was never completed.
 extern "C" int ss_csr_build_cached(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                                    int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
                                    int32_t *mega_rows, int32_t *mega_count, int32_t *err_flag, void *workspace, size_t workspace_bytes,
@@ -1920,14 +1542,20 @@ extern "C" int ss_csr_build_cached(const int64_t *src, const int64_t *dst, int64
 {
     using namespace ss;
     if (!fingerprint || E <= 0 || N <= 0 || !src || !dst) return SS_ERR_INVALID_ARG;
+    LevelPlan lp;
+    int rc = csr_check(src, dst, E, N, rowptr, col, hub_rows, hub_count, mega_rows, mega_count, workspace, workspace_bytes, lp);
+    if (rc != SS_OK) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     FingerprintWords *fp = reinterpret_cast<FingerprintWords *>(fingerprint);
     hipLaunchKernelGGL(fingerprint_kernel, dim3(kFpBlocks), dim3(256), 0, stream, src, dst, E, fp);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(fingerprint_decide_kernel, dim3(1), dim3(kFpBlocks), 0, stream, fp, E, N, (int)hub_threshold, err_flag);
-    SS_LAUNCH_CHECK();
-    return csr_build_impl(src, dst, E, N, rowptr, col, n_self_loops_out, hub_threshold, hub_rows, hub_count, mega_rows, mega_count, err_flag,
-                          workspace, workspace_bytes, stream_, &fp->skip, &fp->bad);
+    rc = hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_LAUNCH;
+    if (rc == SS_OK)
+        rc = csr_build_launch(lp, src, dst, E, N, rowptr, col, n_self_loops_out, hub_threshold, hub_rows, hub_count, mega_rows, mega_count, err_flag,
+                              workspace, stream, &fp->skip, &fp->bad);
+    if (rc != SS_OK) (void)hipMemsetAsync(&fp->valid, 0, sizeof(fp->valid), stream);  // the outputs may be half-written
+    return rc;
 }
 
 // The pairs of a query grouped by their first node (reference hashing.py:270-274 reads cards[u] / the rows of u once per PAIR;
@@ -1940,61 +1568,9 @@ extern "C" int ss_group_links_by_source(const int64_t *links, int64_t B, int64_t
                                         size_t workspace_bytes, void *stream)
 {
     if (B < 0 || B >= ((int64_t)1 << 31) || N <= 0 || (B > 0 && (!links || !order))) return SS_ERR_INVALID_ARG;
-    return csr_build_impl(nullptr, links, B, N, rowptr, order, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
-                          workspace_bytes, stream);
-}
-
-static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
-                          int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
-                          int32_t *mega_rows, int32_t *mega_count,
-                          int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *skip, int32_t *bad_record)
-{
-    using namespace ss;
-    if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || !rowptr) return SS_ERR_INVALID_ARG;
-    if (E > 0 && (!dst || !col)) return SS_ERR_INVALID_ARG;
-    if ((hub_rows == nullptr) != (hub_count == nullptr)) return SS_ERR_INVALID_ARG;
-    if ((mega_rows == nullptr) != (mega_count == nullptr) || (mega_rows && !hub_rows)) return SS_ERR_INVALID_ARG;
-    CsrPlan p;
-    if (!make_plan(N, E, p)) return SS_ERR_UNSUPPORTED;
-    if (!workspace || workspace_bytes < ss_csr_workspace_bytes(N, E)) return SS_ERR_WORKSPACE;
-    hipStream_t stream = (hipStream_t)stream_;
-    if (N == 0 || E == 0) {
-        if (n_self_loops_out && hipMemsetAsync(n_self_loops_out, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
-        if (hub_count && hipMemsetAsync(hub_count, 0, 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
-        if (mega_count && hipMemsetAsync(mega_count, 0, 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
-        if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 8, stream) != hipSuccess) return SS_ERR_LAUNCH;
-        return SS_OK;
-    }
-    ProfileSpan span(stream, SS_PROF_CSR);  // all launches of this build
-    const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count, skip};
-    if (!p.gather) {  // level plans (1 - 3 tile-sort levels)
-        LevelPlan lp;
-        if (!make_level_plan(N, E, src ? N : E, p.node_shift, lp)) return SS_ERR_UNSUPPORTED;
-        return csr_build_levels(lp, src, dst, E, N, col, reinterpret_cast<unsigned long long *>(n_self_loops_out), rows_out, hub_count,
-                                mega_count, err_flag, workspace, stream, skip, bad_record);
-    }
-    const Workspace w = carve(p, E, workspace);
-    unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
-    // the dense steps loop over the registered shares: no more workgroups than shares can exist
-    const int64_t share_cap = max_dense_shares(E);
-    const unsigned dense_grid = (unsigned)(share_cap < kDenseGrid ? share_cap : kDenseGrid);
-    int helpers = dense_helpers();
-    if ((int64_t)helpers > share_cap) helpers = (int)share_cap;
-    const DenseArgs dense = {w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, helpers};
-    {
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(p.tiles), dim3(kSortThreads), 0, stream, src, dst, E, N, p.node_shift, (int)p.fine_buckets, p.tiles, w.staged_a,
-                           w.tile_off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip, bad_record);
-        SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(finish_gather_kernel, dim3((unsigned)(p.fine_buckets + helpers)), dim3(kFinishThreads), 0, stream, w.staged_a,
-                           w.tile_off, w.tile_max, p.tiles, (int)p.fine_buckets, p.node_shift, N, col, n_self, rows_out, dense);
-        SS_LAUNCH_CHECK();
-        if (helpers) return SS_OK;
-        hipLaunchKernelGGL(dense_count_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, w.staged_a, w.tile_off, p.tiles,
-                           p.node_shift, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, skip);
-        SS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(dense_place_kernel<true>, dim3(dense_grid), dim3(kFinishThreads), 0, stream, w.staged_a, w.tile_off, p.tiles,
-                           p.node_shift, N, w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, col, rows_out);
-        SS_LAUNCH_CHECK();
-        return SS_OK;
-    }
+    ss::LevelPlan lp;
+    const int rc = csr_check(nullptr, links, B, N, rowptr, order, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, lp);
+    if (rc != SS_OK) return rc;
+    return csr_build_launch(lp, nullptr, links, B, N, rowptr, order, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
+                            (hipStream_t)stream);
 }

@@ -32,7 +32,7 @@ def check(csr, ei, n):
 
 
 names = [a for a in sys.argv[1:] if not a.startswith('--')] or ['ppa', 'citation2', 'collab']
-KINDS = ({},) if '--uniform' in sys.argv else ({}, dict(kind='powerlaw', alpha=0.5), dict(kind='powerlaw', alpha=0.9))
+KINDS = ({},) if '--uniform' in sys.argv else (dict(kind='powerlaw', alpha=0.5),) if '--pl05' in sys.argv else ({}, dict(kind='powerlaw', alpha=0.5), dict(kind='powerlaw', alpha=0.9))
 for name in names:
     cfg = bench.CONFIGS[name]
     for kw in KINDS:
