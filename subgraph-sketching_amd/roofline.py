@@ -13,11 +13,31 @@ INFINITY_CACHE_BYTES = 256 << 20  # MALL / L3; FETCH_SIZE counts fabric requests
 
 
 def csr_bytes(N, E):
-    """ss_csr_build, single partition pass + finish (the shape of every BASELINE config): count_keys reads dst (8E);
-    scatter_tiles reads src + dst (16E) and writes the staged int2 pairs (8E); finish reads the staged pairs twice (count,
-    place: 16E) and writes col (4E) + rowptr (8(N+1)).  A second / third partition pass adds 24E each (N > 262 144)."""
-    passes = 1 if N <= 256 * 1024 else 2
-    return 8 * E + (16 * E + 8 * E) + (passes - 1) * (8 * E + 16 * E) + 16 * E + 4 * E + 8 * (N + 1)
+    """ss_csr_build, ALGORITHMIC bytes: the edge list read once (16E), col (4E) and rowptr (8(N+1)) written once.  The level
+    plans move more than that (DESIGN 3.5: one level 16E + 4E + 4E + 4E, two levels 16E + 8E + 8E + 4E + 4E + 4E); the
+    roofline fraction of the build is taken on the algorithmic figure (VERDICT r3 #1)."""
+    return 20 * E + 8 * (N + 1)
+
+
+# random whole-row gathers of 512-byte rows against the size of the table they come from: tools/micro/gather_ceiling.hip on an
+# MI355X (profiles/round4_gather_ceiling.txt; best of its in-flight / grid / rows-per-item settings).  The
+# rate such an access pattern can reach -- Infinity-Cache resident below ~256 MB, HBM resident above.
+GATHER_CEILING_GBS = [(30e6, 8730.0), (60e6, 8120.0), (120e6, 7840.0), (200e6, 7700.0), (295e6, 7650.0), (600e6, 7550.0), (1500e6, 7090.0)]
+
+
+def gather_ceiling_gbs(table_bytes):
+    """measured ceiling (GB/s) of random row gathers from a table of this size: log-linear interpolation of GATHER_CEILING_GBS"""
+    import math
+    pts = GATHER_CEILING_GBS
+    if table_bytes <= pts[0][0]:
+        return pts[0][1]
+    if table_bytes >= pts[-1][0]:
+        return pts[-1][1]
+    for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
+        if x0 <= table_bytes <= x1:
+            t = (math.log(table_bytes) - math.log(x0)) / (math.log(x1) - math.log(x0))
+            return y0 + t * (y1 - y0)
+    return pts[-1][1]
 
 
 def graph_read_bytes(N, E):

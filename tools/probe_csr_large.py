@@ -1,5 +1,5 @@
 """probe: ss_csr_build at ogbl-ppa / ogbl-citation2 size (uniform and rank^-0.5 endpoints): checked against torch
-(rowptr from bincount, every row the same multiset of sources) and timed.  SS_CSR_LEGACY=1 runs the round-3 partition passes."""
+(rowptr from bincount, every row the same multiset of sources) and timed (wall clock per build including the host side: use tools/kstats_cmd.sh for kernel times)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
