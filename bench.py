@@ -162,7 +162,7 @@ def roofline_numbers(rf, bytes_alg, launch_ms, table_bytes, traffic):
     if not launch_ms:
         return {}
     basis, note = bytes_alg, 'algorithmic bytes'
-    if traffic and traffic['bytes_per_launch'] < 0.9 * bytes_alg:  # (within 10 %: counter calibration, not repeats -- algorithmic bytes stand)
+    if traffic and traffic["bytes_per_launch"] < 0.97 * bytes_alg:  # (within 3 %: counter calibration, not repeats -- algorithmic bytes stand)
         basis, note = traffic['bytes_per_launch'], f"fabric bytes of the PMC passes ({traffic['file']}): fewer than the algorithmic bytes, repeats served by the L2"
     achieved = basis / (launch_ms * 1e-3) / 1e9
     ceiling = rf.gather_ceiling_gbs(table_bytes)
@@ -552,7 +552,7 @@ def main():
                 tr = None if sharded_build else profiled_traffic(shape_key(a.config, a.graph, a.alpha), name)
                 if tr:
                     row['traffic_bytes'] = tr['bytes_per_launch']
-                    if tr['bytes_per_launch'] < 0.9 * model[name]:  # repeats served by the L2 (see roofline_numbers)
+                    if tr["bytes_per_launch"] < 0.97 * model[name]:  # repeats served by the L2 (see roofline_numbers)
                         row['frac_of_hbm_peak'] = tr['bytes_per_launch'] / (ms.value * 1e-3) / 1e9 / rf.HBM_PEAK_GBS
                         row['bytes_basis'] = 'fabric bytes of the PMC passes'
             kernel_table[name] = row

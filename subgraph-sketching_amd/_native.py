@@ -33,7 +33,7 @@ class CsrGraphStruct(ctypes.Structure):
                 ('mirror_cards', c_void_p * 7), ('hub_report', c_void_p), ('report_hub_count', c_void_p), ('report_mega_count', c_void_p)]
 
 
-ABI_VERSION = 125  # ss_version() of the library this module's struct mirrors and signatures describe
+ABI_VERSION = 126  # ss_version() of the library this module's struct mirrors and signatures describe
 PROF_MINHASH_HOP, PROF_HLL_HOP, PROF_FIRST_HOP_MH, PROF_FIRST_HOP_HLL, PROF_PAIRS, PROF_CSR, PROF_HUB, PROF_FUSED, PROF_MINHASH_ROWS = range(9)  # SS_PROF_* tags
 MEGA_SLICE, MEGA_SLOT_BYTES, CSR_FINGERPRINT_BYTES, MAX_MIRRORS = 1024, 1280, 8448, 7  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
 
@@ -75,6 +75,11 @@ SIGNATURES = {
     'ss_common_neighbour_scores': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                              c_void_p]),
     'ss_spmm_csr': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
+    'ss_csr_group_ids': (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ss_csr_sort_workspace_bytes': (c_size_t, [c_int64]),
+    'ss_csr_sort_rows': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    'ss_gcn_degree': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    'ss_sign_spmm': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     'ss_pack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_unpack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_profile_enable': (c_int32, [c_uint32]),

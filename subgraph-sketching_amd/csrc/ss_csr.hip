@@ -195,11 +195,12 @@ __device__ unsigned long long csr_phase_ticks[16];
 // contiguous) and the tile's max(id) + 1.  A LINK list (ss_group_links_by_source: the pairs of a query grouped by their first node):
 // src == nullptr, dst = links [B, 2] -- the key is the pair's first node, torch-style negative ids wrapped, ids out of range keyed
 // to node 0 (the query kernel itself reports them and writes their NaN rows: nothing may be dropped here), the "source" is the
-// pair's index.
+// pair's index.  The same with key_stride = 1 groups the entries of any id array (ss_csr_group_ids).
 // PACKED (the only level of a one-level plan whose ids fit): records are src | (dst & (2^shift - 1)) << src_bits, 4 bytes
 template <bool PACKED>
 __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, int64_t E,
-                                                                 int64_t N, int shift, int src_bits, int keys, int tiles, void *__restrict__ staged_,
+                                                                 int64_t N, int key_stride, int shift, int src_bits, int keys, int tiles,
+                                                                 void *__restrict__ staged_,
                                                                  uint32_t *__restrict__ tile_off, unsigned long long *__restrict__ tile_max,
                                                                  int32_t *__restrict__ err, int32_t *__restrict__ hub_count,
                                                                  int32_t *__restrict__ mega_count, int32_t *__restrict__ dense_count,
@@ -256,11 +257,12 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
             const int64_t e = t0 + threadIdx.x + (int64_t)k * kSortThreads;
             ok[k] = e < hi;
             sv[k] = ok[k] ? e : t0;
-            dv[k] = dst[2 * sv[k]];
+            dv[k] = dst[(int64_t)key_stride * sv[k]];
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int64_t u = dv[k] < 0 ? dv[k] + N : dv[k];
+            if (ok[k] && (uint64_t)u >= (uint64_t)N) bad = true;  // (reported; the entry stays, keyed to node 0)
             dv[k] = (uint64_t)u < (uint64_t)N ? u : 0;
         }
     }
@@ -1433,7 +1435,7 @@ static int csr_check(const int64_t *src, const int64_t *dst, int64_t E, int64_t 
 static int csr_build_launch(const ss::LevelPlan &lp, const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                             int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count, int32_t *mega_rows,
                             int32_t *mega_count, int32_t *err_flag, void *workspace, hipStream_t stream, const int32_t *skip = nullptr,
-                            int32_t *bad_record = nullptr)
+                            int32_t *bad_record = nullptr, int key_stride = 2)
 {
     using namespace ss;
     if (N == 0 || E == 0) {
@@ -1450,10 +1452,10 @@ static int csr_build_launch(const ss::LevelPlan &lp, const int64_t *src, const i
     const int tiles0 = (int)lp.tmax[0];
     const bool packed = lp.packed;  // records of the last level (read by the finish step) are 4 bytes
     if (packed && lp.levels == 1)
-        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(tiles0), dim3(kSortThreads), 0, stream, src, dst, E, N, lp.shift[0], lp.src_bits, lp.keys[0],
+        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(tiles0), dim3(kSortThreads), 0, stream, src, dst, E, N, key_stride, lp.shift[0], lp.src_bits, lp.keys[0],
                            tiles0, (void *)w.staged_a, w.lv[0].off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip, bad_record);
     else
-        hipLaunchKernelGGL(tile_sort_kernel<false>, dim3(tiles0), dim3(kSortThreads), 0, stream, src, dst, E, N, lp.shift[0], lp.src_bits, lp.keys[0],
+        hipLaunchKernelGGL(tile_sort_kernel<false>, dim3(tiles0), dim3(kSortThreads), 0, stream, src, dst, E, N, key_stride, lp.shift[0], lp.src_bits, lp.keys[0],
                            tiles0, (void *)w.staged_a, w.lv[0].off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, skip, bad_record);
     SS_LAUNCH_CHECK();
     ParentLevel par = {w.lv[0].off, nullptr, nullptr, nullptr, tiles0, tiles0, lp.keys[0], -1};
@@ -1573,4 +1575,177 @@ extern "C" int ss_group_links_by_source(const int64_t *links, int64_t B, int64_t
     if (rc != SS_OK) return rc;
     return csr_build_launch(lp, nullptr, links, B, N, rowptr, order, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
                             (hipStream_t)stream);
+}
+
+// The entries of an id array grouped by id: order[0 .. E) is a permutation of the entry indices in which all entries with the
+// same id are consecutive (rowptr [N + 1] says where each id's group starts), in unspecified order inside a group -- follow with
+// ss_csr_sort_rows for ascending entry indices, i.e. a STABLE grouping (reference datasets/elph.py:87-110: gcn_norm's degree sums
+// and torch_sparse.spmm's scatter-add both accumulate in edge order; sign.py groups the edge list by column and by row).  Ids out
+// of [0, N) (after torch-style negative wrapping) are reported through err_flag and keyed to node 0.  Workspace: ss_csr_workspace_bytes(N, E).
+extern "C" int ss_csr_group_ids(const int64_t *ids, int64_t E, int64_t N, int32_t *order, int64_t *rowptr, int32_t *err_flag, void *workspace,
+                                size_t workspace_bytes, void *stream)
+{
+    if (E < 0 || E >= ((int64_t)1 << 31) || N <= 0 || (E > 0 && (!ids || !order))) return SS_ERR_INVALID_ARG;
+    ss::LevelPlan lp;
+    const int rc = csr_check(nullptr, ids, E, N, rowptr, order, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, lp);
+    if (rc != SS_OK) return rc;
+    return csr_build_launch(lp, nullptr, ids, E, N, rowptr, order, nullptr, 0, nullptr, nullptr, nullptr, nullptr, err_flag, workspace,
+                            (hipStream_t)stream, nullptr, nullptr, 1);
+}
+
+namespace ss {
+
+// ---- rows of a CSR sorted ascending ----------------------------------------------------------------------------------------------
+// compare-exchange network over the low `G` lanes of a lane group (G = 16 or 64, a power of two): ascending
+template <int G>
+__device__ __forceinline__ int bitonic_lanes(int v, int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= G; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int o = __shfl_xor(v, j);
+            const bool up = (lane & k) == 0, low = (lane & j) == 0;
+            v = (low == up) ? (v < o ? v : o) : (v > o ? v : o);
+        }
+    return v;
+}
+
+// rows of at most 64 entries: four rows per wavefront (16 lanes each) where all four have at most 16 entries, else one after the
+// other over the whole wavefront; longer rows are listed for sort_rows_long_kernel
+__global__ __launch_bounds__(256) void sort_rows_short_kernel(const int64_t *__restrict__ rowptr, int32_t *__restrict__ col, int64_t N,
+                                                              int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const int64_t r0 = wave * 4;
+    if (r0 >= N) return;
+    // lanes 0..4 read the five row bounds of this wavefront's four rows
+    const int64_t my = lane <= 4 ? rowptr[r0 + lane < N ? r0 + lane : N] : 0;
+    int64_t b[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) b[k] = __shfl(my, k);
+    const int64_t max_len = [&] { int64_t m = 0; for (int k = 0; k < 4; ++k) m = b[k + 1] - b[k] > m ? b[k + 1] - b[k] : m; return m; }();
+    if (max_len <= 16) {  // (wave-uniform)
+        const int g = lane >> 4, l = lane & 15;
+        const int64_t a = b[0] + 0 * g;  // (keep b[] in SGPRs: select by comparisons)
+        const int64_t lo = g == 0 ? b[0] : g == 1 ? b[1] : g == 2 ? b[2] : b[3];
+        const int64_t hi = g == 0 ? b[1] : g == 1 ? b[2] : g == 2 ? b[3] : b[4];
+        (void)a;
+        const int len = (int)(hi - lo);
+        int v = l < len ? col[lo + l] : 0x7FFFFFFF;
+        if (len > 1) v = bitonic_lanes<16>(v, l);  // (the whole 16-lane group takes the same branch)
+        if (l < len) col[lo + l] = v;
+        return;
+    }
+    for (int k = 0; k < 4; ++k) {
+        const int64_t lo = b[k], len = b[k + 1] - b[k];
+        if (len > kWave) {
+            if (lane == 0) long_rows[atomicAdd(n_long, 1)] = (int32_t)(r0 + k);
+            continue;
+        }
+        if (len < 2) continue;
+        int v = lane < len ? col[lo + lane] : 0x7FFFFFFF;
+        v = bitonic_lanes<kWave>(v, lane);
+        if (lane < len) col[lo + lane] = v;
+    }
+}
+
+// rows above 64 entries, one workgroup each (grid-stride over the list): bitonic sort in LDS up to 16 384 entries; longer rows (hub
+// rows of power-law graphs) are sorted in LDS chunk by chunk and the chunks merged pairwise (merge path: every thread finds where
+// its stretch of the output begins in both runs by a binary search along a diagonal, then merges sequentially), ping-ponging
+// between col and scratch (the row's own stretch of an E-entry scratch array)
+constexpr int kSortRowLds = 16384;
+
+// ascending bitonic sort of buf[0 .. n2), n2 a power of two <= kSortRowLds (all 1024 threads)
+__device__ __forceinline__ void bitonic_lds(int32_t *buf, int n2)
+{
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const int32_t a = buf[i], c = buf[p];
+                    if ((a > c) == ((i & k) == 0)) { buf[i] = c; buf[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(1024) void sort_rows_long_kernel(const int64_t *__restrict__ rowptr, int32_t *__restrict__ col,
+                                                              int32_t *__restrict__ scratch, const int32_t *__restrict__ long_rows,
+                                                              const int32_t *__restrict__ n_long)
+{
+    __shared__ int32_t buf[kSortRowLds];
+    const int n_rows = *n_long;
+    for (int q = blockIdx.x; q < n_rows; q += gridDim.x) {
+        const int64_t lo = rowptr[long_rows[q]], len = rowptr[long_rows[q] + 1] - lo;
+        int32_t *base = col + lo;
+        for (int64_t c0 = 0; c0 < len; c0 += kSortRowLds) {  // sorted chunks of up to 16 384 entries
+            const int n = (int)(len - c0 < kSortRowLds ? len - c0 : kSortRowLds);
+            int n2 = 1;
+            while (n2 < n) n2 <<= 1;
+            for (int i = threadIdx.x; i < n2; i += 1024) buf[i] = i < n ? base[c0 + i] : 0x7FFFFFFF;
+            __syncthreads();
+            bitonic_lds(buf, n2);
+            for (int i = threadIdx.x; i < n; i += 1024) base[c0 + i] = buf[i];
+            __syncthreads();
+        }
+        int32_t *src = base, *dst = scratch + lo;
+        for (int64_t width = kSortRowLds; width < len; width <<= 1) {  // pairwise merges of runs of `width`
+            for (int64_t s0 = 0; s0 < len; s0 += 2 * width) {
+                const int64_t na = len - s0 < width ? len - s0 : width, nb = len - s0 - na < width ? len - s0 - na : width;
+                const int32_t *A = src + s0, *Bp = A + na;
+                int32_t *O = dst + s0;
+                const int64_t m = na + nb, per = (m + 1023) / 1024;
+                const int64_t d0 = per * threadIdx.x < m ? per * threadIdx.x : m, d1 = d0 + per < m ? d0 + per : m;
+                // merge path: the number i of A's entries among the first d0 outputs (ties: A first -- the sort need not be
+                // stable, the entries of a row are distinct positions / may repeat harmlessly)
+                int64_t a_lo = d0 > nb ? d0 - nb : 0, a_hi = d0 < na ? d0 : na;
+                while (a_lo < a_hi) {
+                    const int64_t i = (a_lo + a_hi) >> 1;  // try i entries of A, d0 - i of B
+                    if (A[i] <= Bp[d0 - i - 1]) a_lo = i + 1; else a_hi = i;
+                }
+                int64_t i = a_lo, j = d0 - a_lo;
+                for (int64_t o = d0; o < d1; ++o) {
+                    const bool take_a = j >= nb || (i < na && A[i] <= Bp[j]);
+                    O[o] = take_a ? A[i++] : Bp[j++];
+                }
+            }
+            __syncthreads();
+            int32_t *t = src; src = dst; dst = t;
+        }
+        if (src != base) {
+            for (int64_t i = threadIdx.x; i < len; i += 1024) base[i] = src[i];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace ss
+
+// Every row of a CSR sorted ascending in place (col of rows [0, N)).  With the entry indices as payload (ss_csr_group_ids,
+// ss_group_links_by_source) that makes the grouping STABLE -- the reference's edge order inside every group; with source ids it
+// gives the sorted adjacency scipy / torch_sparse hold.  Workspace: ss_csr_sort_workspace_bytes(E) device bytes.
+extern "C" size_t ss_csr_sort_workspace_bytes(int64_t E) { return E < 0 ? 0 : (size_t)(E / ss::kWave + 2) * 4 + 256 + (size_t)(E > 0 ? E : 1) * 4; }
+
+extern "C" int ss_csr_sort_rows(const int64_t *rowptr, int32_t *col, int64_t N, int64_t E, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace ss;
+    if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || E >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
+    if (N == 0 || E == 0) return SS_OK;
+    if (!rowptr || !col) return SS_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < ss_csr_sort_workspace_bytes(E)) return SS_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    int32_t *n_long = reinterpret_cast<int32_t *>(workspace);
+    int32_t *long_rows = n_long + 64;  // (its own cache lines)
+    int32_t *scratch = long_rows + (E / kWave + 2);
+    if (hipMemsetAsync(n_long, 0, 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
+    const int64_t waves = (N + 3) / 4;
+    hipLaunchKernelGGL(sort_rows_short_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, rowptr, col, N, long_rows, n_long);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sort_rows_long_kernel, dim3(512), dim3(1024), 0, stream, rowptr, col, scratch, long_rows, n_long);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
 }

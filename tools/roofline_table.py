@@ -61,6 +61,15 @@ def main():
         else:
             lines.append(f'| `{short}` | {r["Calls"]} | {avg / 1e3:.1f} | - | - | - | {hbm / 1e6:.2f} MB | - | - |' if hbm else
                          f'| `{short}` | {r["Calls"]} | {avg / 1e3:.1f} | - | - | - | - | - | - |')
+    # the CSR build as one family: its kernels summed (one launch of each per build) against the algorithmic 20E + 8N
+    csr_keys = ('tile_sort_kernel', 'regroup_sort_kernel', 'finish_runs_kernel', 'level_scan_kernel', 'level_tiles_kernel', 'level_fill_kernel',
+                'dense_count_runs_kernel', 'dense_place_runs_kernel')
+    csr_us = sum(float(r['AverageNs']) for nme, r in stats.items() if any(k in nme for k in csr_keys)) / 1e3
+    csr_pmc = sum((2 * v.get('FETCH_SIZE_KB_avg', 0) + v.get('WRITE_SIZE_KB_avg', 0)) * 1024 for k, v in pmc.items() if any(c in k for c in csr_keys))
+    if csr_us:
+        alg = model['csr_build']
+        lines.append(f'| **CSR build: the kernels above it is made of, summed** | 1 each | {csr_us:.1f} | {alg / 1e9:.4f} GB (20E + 8N) | {alg / csr_us / 1e3:.0f} | '
+                     f'{alg / csr_us / 1e3 / rf.HBM_PEAK_GBS:.3f} | ' + (f'{csr_pmc / 1e9:.4f} GB | {csr_pmc / alg:.2f} | - |' if csr_pmc else '- | - | - |'))
     calls = max(int(r['Calls']) for nme, r in stats.items() if 'propagate_kernel<128' in nme) // max(h - 1, 1)
     step_us = ours_ns / 1e3 / calls
     lines += ['', f'Sum of the engine\'s kernels per step (kernel time only, {calls} steps traced): **{step_us:.1f} us**; bytes of the implemented '
