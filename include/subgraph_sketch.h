@@ -270,18 +270,24 @@ int ss_spmm_csr(const int64_t *rowptr, const int32_t *col, const float *val, int
  * scatter-add accumulate in edge order -- sign.py groups the edge list by column and by row) */
 int ss_csr_group_ids(const int64_t *ids, int64_t E, int64_t N, int32_t *order, int64_t *rowptr, int32_t *err_flag, void *workspace,
                      size_t workspace_bytes, void *stream);
-/* every row of a CSR sorted ascending in place; workspace: ss_csr_sort_workspace_bytes(E) device bytes */
+/* every row of a CSR sorted ascending in place; workspace: ss_csr_sort_workspace_bytes(E) device bytes.  only_if (nullable): a
+ * device word -- the rows are sorted only if it is non-zero when the launches run */
 size_t ss_csr_sort_workspace_bytes(int64_t E);
-int ss_csr_sort_rows(const int64_t *rowptr, int32_t *col, int64_t N, int64_t E, void *workspace, size_t workspace_bytes, void *stream);
+int ss_csr_sort_rows(const int64_t *rowptr, int32_t *col, int64_t N, int64_t E, const int32_t *only_if, void *workspace, size_t workspace_bytes,
+                     void *stream);
 /* gcn_norm + torch_sparse.spmm of HashDataset._generate_sign_features (reference datasets/elph.py:100-107) without materialising
  * the normalised edge list [PyG semantics restated: add_remaining_self_loops(fill 1), deg = index_add over col, deg^-1/2 with
- * inf -> 0, norm = dinv[row] * w * dinv[col]].  ss_gcn_degree: dinv / loop_w [N] from the stable grouping by COLUMN;
+ * inf -> 0, norm = dinv[row] * w * dinv[col]].  ss_gcn_scan_edges: one pass over the edge list into `scan` (ss_gcn_scan_bytes(N)
+ * device bytes; its first int32 word: some weight differs from 1) -- unit weights? existing self loops per node.  ss_gcn_degree:
+ * dinv / loop_w [N] from the grouping by COLUMN (stable unless the weights are all 1: then the degrees are counts);
  * ss_sign_spmm: out = A_norm x from the stable grouping by ROW, every output element accumulated by one lane in edge order
  * (existing self loops skipped, the node's remaining loop last), products and sums rounded separately. */
-int ss_gcn_degree(const int64_t *rowptr_c, const int32_t *order_c, const int64_t *row, const float *w, int64_t N, float *dinv,
-                  float *loop_w, void *stream);
+size_t ss_gcn_scan_bytes(int64_t N);
+int ss_gcn_scan_edges(const int64_t *row, const int64_t *col, const float *w, int64_t E, int64_t N, void *scan, void *stream);
+int ss_gcn_degree(const int64_t *rowptr_c, const int32_t *order_c, const int64_t *row, const float *w, int64_t N, const void *scan,
+                  float *dinv, float *loop_w, void *stream);
 int ss_sign_spmm(const int64_t *rowptr_r, const int32_t *order_r, const int64_t *col, const float *w, const float *dinv,
-                 const float *loop_w, int64_t N, const float *x, int32_t F, float *out, void *stream);
+                 const float *loop_w, const void *scan, int64_t N, const float *x, int32_t F, float *out, void *stream);
 
 /* int64 <-> packed uint32 MinHash tables (the reference's tensors are int64, hashing.py:124). */
 int ss_pack_minhash(const int64_t *in, uint32_t *out, int64_t count, void *stream);

@@ -238,10 +238,20 @@ def gcn_norm(edge_index, edge_weight, num_nodes):
     w2 = np.concatenate([w[keep], loop_w]).astype(np.float32)
     deg = np.zeros(num_nodes, dtype=np.float32)
     np.add.at(deg, ei2[1], w2)
-    with np.errstate(divide='ignore'):
-        dinv = np.power(deg, np.float32(-0.5)).astype(np.float32)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        dinv = (np.float32(1.0) / np.sqrt(deg)).astype(np.float32)  # torch evaluates pow(-0.5) as the reciprocal of the square root
     dinv[np.isinf(dinv)] = 0
     return ei2, (dinv[ei2[0]] * w2 * dinv[ei2[1]]).astype(np.float32)
+
+
+def generate_sign_features(x, edge_index, edge_weight, sign_k):
+    """HashDataset._generate_sign_features (reference datasets/elph.py:87-110): gcn_norm, then spmm of data.x -- for sign_k > 0
+    the SAME product sign_k times behind x itself (the loop multiplies data.x every time, :105-107)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.shape[0]
+    ei, wn = gcn_norm(edge_index, np.asarray(edge_weight, dtype=np.float32), n)
+    ax = spmm(ei, wn, n, x)
+    return ax if sign_k == 0 else np.concatenate([x] + [ax] * sign_k, axis=1)
 
 
 def spmm(index, value, n, x):

@@ -77,9 +77,11 @@ SIGNATURES = {
     'ss_spmm_csr': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     'ss_csr_group_ids': (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ss_csr_sort_workspace_bytes': (c_size_t, [c_int64]),
-    'ss_csr_sort_rows': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
-    'ss_gcn_degree': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    'ss_sign_spmm': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
+    'ss_csr_sort_rows': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ss_gcn_scan_bytes': (c_size_t, [c_int64]),
+    'ss_gcn_scan_edges': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    'ss_gcn_degree': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ss_sign_spmm': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     'ss_pack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_unpack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_profile_enable': (c_int32, [c_uint32]),

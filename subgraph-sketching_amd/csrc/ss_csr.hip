@@ -1614,8 +1614,10 @@ __device__ __forceinline__ int bitonic_lanes(int v, int lane)
 // rows of at most 64 entries: four rows per wavefront (16 lanes each) where all four have at most 16 entries, else one after the
 // other over the whole wavefront; longer rows are listed for sort_rows_long_kernel
 __global__ __launch_bounds__(256) void sort_rows_short_kernel(const int64_t *__restrict__ rowptr, int32_t *__restrict__ col, int64_t N,
-                                                              int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long)
+                                                              int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long,
+                                                              const int32_t *__restrict__ keep_word)
 {
+    if (keep_word && *keep_word == 0) return;  // (see ss_csr_sort_rows)
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
     const int64_t r0 = wave * 4;
@@ -1730,7 +1732,10 @@ __global__ __launch_bounds__(1024) void sort_rows_long_kernel(const int64_t *__r
 // gives the sorted adjacency scipy / torch_sparse hold.  Workspace: ss_csr_sort_workspace_bytes(E) device bytes.
 extern "C" size_t ss_csr_sort_workspace_bytes(int64_t E) { return E < 0 ? 0 : (size_t)(E / ss::kWave + 2) * 4 + 256 + (size_t)(E > 0 ? E : 1) * 4; }
 
-extern "C" int ss_csr_sort_rows(const int64_t *rowptr, int32_t *col, int64_t N, int64_t E, void *workspace, size_t workspace_bytes, void *stream_)
+// only_if (nullable): device word; the rows are sorted only if it is NON-zero when the launches run (sign.py: the grouping by column
+// needs its order only when some edge weight differs from 1 -- ss_gcn_scan_edges leaves that in the first word of its buffer)
+extern "C" int ss_csr_sort_rows(const int64_t *rowptr, int32_t *col, int64_t N, int64_t E, const int32_t *only_if, void *workspace,
+                                size_t workspace_bytes, void *stream_)
 {
     using namespace ss;
     if (N < 0 || E < 0 || N >= ((int64_t)1 << 31) || E >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
@@ -1743,7 +1748,7 @@ extern "C" int ss_csr_sort_rows(const int64_t *rowptr, int32_t *col, int64_t N, 
     int32_t *scratch = long_rows + (E / kWave + 2);
     if (hipMemsetAsync(n_long, 0, 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
     const int64_t waves = (N + 3) / 4;
-    hipLaunchKernelGGL(sort_rows_short_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, rowptr, col, N, long_rows, n_long);
+    hipLaunchKernelGGL(sort_rows_short_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, rowptr, col, N, long_rows, n_long, only_if);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(sort_rows_long_kernel, dim3(512), dim3(1024), 0, stream, rowptr, col, scratch, long_rows, n_long);
     SS_LAUNCH_CHECK();

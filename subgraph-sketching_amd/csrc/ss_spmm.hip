@@ -63,85 +63,142 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int64_t *__restric
 // torch_sparse.spmm then computes out[row_e] += norm_e * x[col_e] in edge order.  Both accumulations are reproduced bit for bit
 // from STABLE groupings of the edge indices (ss_csr_group_ids + ss_csr_sort_rows): by column for the degrees, by row for the product.
 
-// one 16-lane group per node: the weights of its in-edges summed in edge order (lane 0 adds, 16 loads at a time)
-__global__ __launch_bounds__(256) void gcn_degree_kernel(const int64_t *__restrict__ rowptr_c, const int32_t *__restrict__ order_c,
-                                                         const int64_t *__restrict__ row, const float *__restrict__ w, int64_t N,
-                                                         float *__restrict__ dinv, float *__restrict__ loop_w)
+// one pass over the edge list: are all weights exactly 1 (then every degree is a count and no order matters), the existing self loops
+// per node (count, and the index of the LAST one: add_remaining_self_loops is a scatter assignment in edge order)
+struct GcnScan {
+    int32_t not_unit;   // some weight differs from 1.0f
+    int32_t pad[63];
+};
+__global__ __launch_bounds__(256) void gcn_scan_edges_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
+                                                             const float *__restrict__ w, int64_t E, int64_t N, GcnScan *__restrict__ scan,
+                                                             int32_t *__restrict__ self_count, int32_t *__restrict__ last_self)
 {
-    const int l = threadIdx.x & (kRow - 1);
-    const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kRow;
-    if (c >= N) return;
-    const int64_t e0 = rowptr_c[c], e1 = rowptr_c[c + 1];
-    float deg = 0.0f, lw = 1.0f;
-    const int base = (threadIdx.x & (kWave - 1)) & ~(kRow - 1);
-    for (int64_t j0 = e0; j0 < e1; j0 += kRow) {
-        const int64_t j = j0 + l;
-        const int32_t e = order_c[j < e1 ? j : e0];
-        const float we = w[e];
-        const bool self = row[e] == c;
-        const int n = (int)(e1 - j0 < kRow ? e1 - j0 : kRow);
-        for (int k = 0; k < n; ++k) {  // (group-uniform trip count)
-            const float wk = __shfl(we, base + k);
-            const bool sk = __shfl((int)self, base + k) != 0;
-            if (sk) lw = wk; else deg += wk;
+    bool odd = false;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = row[e], c = col[e];
+        odd |= w[e] != 1.0f;
+        if (r == c && (uint64_t)r < (uint64_t)N) {
+            atomicAdd(&self_count[r], 1);
+            atomicMax(&last_self[r], (int32_t)e);
         }
     }
-    deg += lw;
-    if (l == 0) {
-        float d = 1.0f / sqrtf(deg);  // deg.pow(-0.5): torch evaluates it as the reciprocal of the square root, both correctly rounded
+    if (__ballot(odd) && (threadIdx.x & (kWave - 1)) == 0) scan->not_unit = 1;  // (plain store of the same value by whoever sees one)
+}
+
+// dinv / loop_w per node.  Unit weights (scan->not_unit == 0): deg = (entries of the column group - existing self loops) + loop weight,
+// exact in fp32 up to 2^24 -- the order of a sum of ones does not matter, and the group need not be sorted.  Otherwise one 16-lane
+// group per node: the weights of its in-edges summed in edge order (lane by lane, 16 loads at a time).
+__global__ __launch_bounds__(256) void gcn_degree_kernel(const int64_t *__restrict__ rowptr_c, const int32_t *__restrict__ order_c,
+                                                         const int64_t *__restrict__ row, const float *__restrict__ w, int64_t N,
+                                                         const GcnScan *__restrict__ scan, const int32_t *__restrict__ self_count,
+                                                         const int32_t *__restrict__ last_self, float *__restrict__ dinv,
+                                                         float *__restrict__ loop_w)
+{
+    const bool unit = scan->not_unit == 0;  // (uniform)
+    if (unit) {
+        const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (c >= N) return;
+        const int32_t ls = last_self[c];
+        const float lw = ls >= 0 ? w[ls] : 1.0f;
+        const float deg = (float)(int)(rowptr_c[c + 1] - rowptr_c[c] - self_count[c]) + lw;
+        float d = 1.0f / sqrtf(deg);
         if (isinf(d)) d = 0.0f;
         dinv[c] = d;
         loop_w[c] = lw;
+        return;
+    }
+    const int l = threadIdx.x & (kRow - 1);
+    for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kRow; c < N; c += (int64_t)gridDim.x * blockDim.x / kRow) {
+        const int64_t e0 = rowptr_c[c], e1 = rowptr_c[c + 1];
+        const int32_t ls = last_self[c];
+        const float lw = ls >= 0 ? w[ls] : 1.0f;
+        float deg = 0.0f;
+        const int base = (threadIdx.x & (kWave - 1)) & ~(kRow - 1);
+        for (int64_t j0 = e0; j0 < e1; j0 += kRow) {
+            const int64_t j = j0 + l;
+            const int32_t e = order_c[j < e1 ? j : e0];
+            const float we = row[e] == c ? 0.0f : w[e];  // (an existing self loop is not part of the sum; 0 is added exactly ... but
+            const bool self = row[e] == c;               //  -0 / NaN weights would not be: skip it instead)
+            const int n = (int)(e1 - j0 < kRow ? e1 - j0 : kRow);
+            for (int k = 0; k < n; ++k) {  // (group-uniform trip count)
+                const float wk = __shfl(we, base + k);
+                if (!__shfl((int)self, base + k)) deg += wk;
+            }
+        }
+        deg += lw;
+        if (l == 0) {
+            float d = 1.0f / sqrtf(deg);  // deg.pow(-0.5): torch evaluates it as the reciprocal of the square root, both correctly rounded
+            if (isinf(d)) d = 0.0f;
+            dinv[c] = d;
+            loop_w[c] = lw;
+        }
     }
 }
 
 // spmm_rows_kernel with the normalised weights formed on the fly: row i's entries are the edge indices e (ascending) with
-// row[e] == i; existing self loops are skipped, the node's one remaining loop comes last
+// row[e] == i; existing self loops are skipped, the node's one remaining loop comes last.  The lanes of a row first fetch one entry
+// each (edge index -> column, weight -> the column's dinv: three dependent loads, once per lanes_per_row entries instead of once
+// per batch of four) and hand them out with shuffles; the feature rows are then requested four at a time.
 __global__ __launch_bounds__(256) void sign_spmm_kernel(const int64_t *__restrict__ rowptr_r, const int32_t *__restrict__ order_r,
                                                         const int64_t *__restrict__ col, const float *__restrict__ w,
                                                         const float *__restrict__ dinv, const float *__restrict__ loop_w, int64_t N,
-                                                        const float *__restrict__ x, int F, float *__restrict__ out, int lanes_per_row)
+                                                        const float *__restrict__ x, int F, float *__restrict__ out, int lanes_per_row,
+                                                        const GcnScan *__restrict__ scan)
 {
+    const bool unit = scan->not_unit == 0;  // (uniform) all weights are 1: w[e] need not be gathered (a 64-byte sector per entry)
     const int lane = threadIdx.x & (kWave - 1);
     const int rows_per_wave = kWave / lanes_per_row;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-    const int64_t i = wave * rows_per_wave + lane / lanes_per_row;
-    if (i >= N) return;
-    const int cl = lane % lanes_per_row;
+    const int64_t i_raw = wave * rows_per_wave + lane / lanes_per_row;
+    const int64_t i = i_raw < N ? i_raw : N - 1;  // (lanes past the end shadow the last row and do not store: shuffles need every lane)
+    const int cl = lane % lanes_per_row, base = lane - cl;
     const int64_t e0 = rowptr_r[i], e1 = rowptr_r[i + 1];
     const int CF = F >> 2;  // float4 chunks per row
     const float di = dinv[i];
-    for (int c = cl; c < CF; c += lanes_per_row) {
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (int64_t j0 = e0; j0 < e1; j0 += 4) {  // four feature rows requested before the first is used; the adds stay in edge order
-            float4 r[4];
-            float nw[4];
-            bool use[4];
+    const int c4 = cl < CF ? cl : 0;  // (F / 4 <= 64: one chunk per lane when lanes_per_row == pow2_ceil(F / 4); wider rows loop below)
+    float4 acc[1] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+    for (int cbase = 0; cbase < CF; cbase += lanes_per_row) {  // (one iteration unless F > 256)
+        const int c = cbase + c4;
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int64_t j0 = e0; j0 < e1; j0 += lanes_per_row) {
+            // this lane's entry of the stretch
+            const int64_t j = j0 + cl;
+            const int32_t e = order_r[j < e1 ? j : e0];
+            const int64_t my_c = col[e];
+            const float my_nw = di * (unit ? 1.0f : w[e]) * dinv[my_c];
+            const int my_use = j < e1 && my_c != i;
+            const int n = (int)(e1 - j0 < lanes_per_row ? e1 - j0 : lanes_per_row);
+            for (int k0 = 0; k0 < n; k0 += 4) {  // (uniform per row group)
+                float4 r[4];
+                float nw[4];
+                int use[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int32_t e = order_r[j0 + k < e1 ? j0 + k : e0];  // (a valid entry for the slots past the end; not used)
-                const int64_t cj = col[e];
-                use[k] = j0 + k < e1 && cj != i;
-                nw[k] = di * w[e] * dinv[cj];
-                r[k] = *reinterpret_cast<const float4 *>(x + cj * F + 4 * c);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (use[k]) {
-                    acc.x += r[k].x * nw[k];
-                    acc.y += r[k].y * nw[k];
-                    acc.z += r[k].z * nw[k];
-                    acc.w += r[k].w * nw[k];
+                for (int k = 0; k < 4; ++k) {
+                    const int src = base + (k0 + k < lanes_per_row ? k0 + k : 0);
+                    const int64_t cj = ((int64_t)__shfl((int)(my_c >> 32), src) << 32) | (uint32_t)__shfl((int)my_c, src);
+                    nw[k] = __shfl(my_nw, src);
+                    use[k] = k0 + k < n ? __shfl(my_use, src) : 0;
+                    r[k] = *reinterpret_cast<const float4 *>(x + (use[k] ? cj : i) * F + 4 * c);
                 }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (use[k]) {
+                        a.x += r[k].x * nw[k];
+                        a.y += r[k].y * nw[k];
+                        a.z += r[k].z * nw[k];
+                        a.w += r[k].w * nw[k];
+                    }
+            }
         }
         const float nl = di * loop_w[i] * di;
         const float4 rs = *reinterpret_cast<const float4 *>(x + i * F + 4 * c);
-        acc.x += rs.x * nl;
-        acc.y += rs.y * nl;
-        acc.z += rs.z * nl;
-        acc.w += rs.w * nl;
-        *reinterpret_cast<float4 *>(out + i * F + 4 * c) = acc;
+        a.x += rs.x * nl;
+        a.y += rs.y * nl;
+        a.z += rs.z * nl;
+        a.w += rs.w * nl;
+        if (i_raw < N && cbase + cl < CF) *reinterpret_cast<float4 *>(out + i * F + 4 * c) = a;
     }
+    (void)acc;
 }
 
 }  // namespace ss
@@ -164,37 +221,60 @@ extern "C" int ss_spmm_csr(const int64_t *rowptr, const int32_t *col, const floa
 }
 
 // dinv[c] = (sum of the weights into c, existing self loops replaced by one loop of their weight or 1)^-1/2 (inf -> 0) and that loop's
-// weight, from the STABLE grouping of the edge indices by column (rowptr_c / order_c: ss_csr_group_ids(edge_index[1]) +
-// ss_csr_sort_rows); row = edge_index[0] (device int64[E]), w device fp32[E].  (reference datasets/elph.py:100-101: gcn_norm)
-extern "C" int ss_gcn_degree(const int64_t *rowptr_c, const int32_t *order_c, const int64_t *row, const float *w, int64_t N, float *dinv,
-                             float *loop_w, void *stream)
+// weight.  ss_gcn_scan_edges first (one pass over the edge list: unit weights? existing self loops per node) into `scan`
+// (SS_GCN_SCAN_BYTES(N) device bytes); ss_gcn_degree then reads the grouping of the edge indices by column (rowptr_c / order_c:
+// ss_csr_group_ids(edge_index[1]) -- STABLE, i.e. followed by ss_csr_sort_rows, unless the weights are all 1: pass scan as that
+// call's `skip`).  row = edge_index[0] (device int64[E]), w device fp32[E].  (reference datasets/elph.py:100-101: gcn_norm)
+extern "C" size_t ss_gcn_scan_bytes(int64_t N) { return N < 0 ? 0 : sizeof(ss::GcnScan) + (size_t)N * 8; }
+
+extern "C" int ss_gcn_scan_edges(const int64_t *row, const int64_t *col, const float *w, int64_t E, int64_t N, void *scan, void *stream_)
+{
+    using namespace ss;
+    if (N < 0 || E < 0 || !scan) return SS_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    GcnScan *sc = reinterpret_cast<GcnScan *>(scan);
+    int32_t *self_count = reinterpret_cast<int32_t *>(sc + 1), *last_self = self_count + N;
+    if (hipMemsetAsync(scan, 0, sizeof(GcnScan) + (size_t)N * 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
+    if (N && hipMemsetAsync(last_self, 0xFF, (size_t)N * 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
+    if (E == 0) return SS_OK;
+    if (!row || !col || !w) return SS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(gcn_scan_edges_kernel, dim3(2048), dim3(256), 0, stream, row, col, w, E, N, sc, self_count, last_self);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+extern "C" int ss_gcn_degree(const int64_t *rowptr_c, const int32_t *order_c, const int64_t *row, const float *w, int64_t N, const void *scan,
+                             float *dinv, float *loop_w, void *stream)
 {
     using namespace ss;
     if (N < 0 || N >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
     if (N == 0) return SS_OK;
-    if (!rowptr_c || !order_c || !row || !w || !dinv || !loop_w) return SS_ERR_INVALID_ARG;
-    const int64_t blocks = (N * kRow + 255) / 256;
-    hipLaunchKernelGGL(gcn_degree_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr_c, order_c, row, w, N, dinv, loop_w);
+    if (!rowptr_c || !order_c || !row || !w || !scan || !dinv || !loop_w) return SS_ERR_INVALID_ARG;
+    const GcnScan *sc = reinterpret_cast<const GcnScan *>(scan);
+    const int32_t *self_count = reinterpret_cast<const int32_t *>(sc + 1), *last_self = self_count + N;
+    const int64_t blocks = (N + 255) / 256;  // (unit weights: one thread per node; else 16-lane groups striding over the nodes)
+    hipLaunchKernelGGL(gcn_degree_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr_c, order_c, row, w, N, sc, self_count,
+                       last_self, dinv, loop_w);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
 // out = gcn_norm(A) * x: the product of reference datasets/elph.py:102-107 without the normalised edge list in memory.
 // rowptr_r / order_r: the STABLE grouping of the edge indices by row (edge_index[0]); col = edge_index[1] (device int64[E]);
-// dinv, loop_w from ss_gcn_degree; x, out fp32 [N, F], F % 4 == 0.
+// dinv, loop_w from ss_gcn_degree, scan from ss_gcn_scan_edges; x, out fp32 [N, F], F % 4 == 0.
 extern "C" int ss_sign_spmm(const int64_t *rowptr_r, const int32_t *order_r, const int64_t *col, const float *w, const float *dinv,
-                            const float *loop_w, int64_t N, const float *x, int32_t F, float *out, void *stream)
+                            const float *loop_w, const void *scan, int64_t N, const float *x, int32_t F, float *out, void *stream)
 {
     using namespace ss;
     if (N < 0 || F <= 0 || (F & 3) || N >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
     if (N == 0) return SS_OK;
-    if (!rowptr_r || !order_r || !col || !w || !dinv || !loop_w || !x || !out) return SS_ERR_INVALID_ARG;
+    if (!rowptr_r || !order_r || !col || !w || !dinv || !loop_w || !scan || !x || !out) return SS_ERR_INVALID_ARG;
     int lanes = pow2_ceil(F >> 2);
     if (lanes > kWave) lanes = kWave;
     const int rows_per_block = (256 / kWave) * (kWave / lanes);
     const int64_t blocks = (N + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(sign_spmm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr_r, order_r, col, w, dinv, loop_w, N, x,
-                       (int)F, out, lanes);
+                       (int)F, out, lanes, reinterpret_cast<const GcnScan *>(scan));
     SS_LAUNCH_CHECK();
     return SS_OK;
 }

@@ -1,11 +1,16 @@
 """Host mirror of HashDataset._generate_sign_features (reference datasets/elph.py:87-110): the
 SIGN-style node-feature preprocessing BUDDY runs once per split -- `gcn_norm` of the adjacency, then `torch_sparse.spmm`.
 
-Both PyG's `gcn_norm` and `torch_sparse.spmm` are absent from this image, so their semantics are RESTATED here (parity
-unpinned for this row): gcn_norm = add_remaining_self_loops(fill 1) + D^-1/2 A D^-1/2 with D the weighted in-degree over
-`col`; spmm(index, value, m, n, x) = scatter_add(value * x[index[1]], index[0]).  The normalisation is elementwise torch
-(plumbing); the product is the hand-written ss_spmm_csr kernel, which accumulates every output element in the
-reference's edge order (see include/subgraph_sketch.h), so only the rounding of deg^-1/2 can differ from a CPU run.
+Both PyG's `gcn_norm` and `torch_sparse.spmm` are absent from this image, so their semantics are RESTATED here: gcn_norm =
+add_remaining_self_loops(fill 1) + D^-1/2 A D^-1/2 with D the weighted in-degree over `col`; spmm(index, value, m, n, x) =
+scatter_add(value * x[index[1]], index[0]).  G15 (tests/golden) pins the reference's OWN _generate_sign_features under that
+restatement; a fixture from the real packages (tools/export_pyg_fixture.py) would pin the restatement itself.
+
+`generate_sign_features` is one chain of library calls (round 4): the edge indices grouped stably by column and by row on the
+device (ss_csr_group_ids + ss_csr_sort_rows: the CSR builder with the edge index as payload), ss_gcn_degree (weighted degrees
+summed in edge order, deg^-1/2), ss_sign_spmm (normalised weights formed on the fly, every output element accumulated in the
+reference's edge order) -- no normalised edge list, no torch sort.  `gcn_norm` and `spmm` stay as the two functions the
+reference calls, for callers that want them separately.
 """
 import torch
 
@@ -30,6 +35,30 @@ def gcn_norm(edge_index, edge_weight, num_nodes):
     return ei, dinv[ei[0]] * w * dinv[ei[1]]
 
 
+def group_ids_stable(ids, num_ids, err=None, only_if=None):
+    """(rowptr int64[num_ids + 1], order int32[E]): the positions of `ids` (device int64[E]) grouped by id, ascending inside every
+    group -- what a stable sort of `ids` gives, built by the CSR builder (ss_csr_group_ids) and a per-row sort (ss_csr_sort_rows).
+    Ids outside [0, num_ids) raise IndexError (one host read of a flag word) unless the caller passes its own `err` word and
+    checks it later.  only_if: device int32 word -- the per-row sort runs only if it is non-zero (else: grouped, any order)."""
+    lib = _native.lib()
+    device = ids.device
+    E = ids.numel()
+    rowptr = torch.empty(num_ids + 1, dtype=torch.int64, device=device)
+    order = torch.empty(max(E, 1), dtype=torch.int32, device=device)
+    own_err = err is None
+    if own_err:
+        err = torch.zeros(1, dtype=torch.int32, device=device)
+    ws_bytes = max(lib.ss_csr_workspace_bytes(num_ids, E), lib.ss_csr_sort_workspace_bytes(E))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=device)
+    _native.check(lib.ss_csr_group_ids(_ptr(ids), E, num_ids, _ptr(order), _ptr(rowptr), _ptr(err), _ptr(ws), ws_bytes, _stream(device)),
+                  'ss_csr_group_ids')
+    _native.check(lib.ss_csr_sort_rows(_ptr(rowptr), _ptr(order), num_ids, E, _ptr(only_if) if only_if is not None else None, _ptr(ws), ws_bytes,
+                                       _stream(device)), 'ss_csr_sort_rows')
+    if own_err and int(err.item()):
+        raise IndexError('ids outside [0, num_ids)')
+    return rowptr, order[:E]
+
+
 def spmm(index, value, m, n, matrix):
     """torch_sparse.spmm(index, value, m, n, matrix): out[index[0]] += value * matrix[index[1]]; [m, F] float32"""
     if m != n or matrix.size(0) != n:
@@ -41,12 +70,11 @@ def spmm(index, value, m, n, matrix):
     pad = (-F) % 4
     if pad:
         x = torch.nn.functional.pad(x, (0, pad))
-    row = index[0].to(device)
-    order = torch.sort(row, stable=True)[1]  # CSR order == the reference's edge order inside every row
+    row = index[0].to(device).contiguous()
+    rowptr, order = group_ids_stable(row, m)  # CSR order == the reference's edge order inside every row
+    order = order.to(torch.int64)
     col = index[1].to(device)[order].to(torch.int32).contiguous()
     val = value.to(device=device, dtype=torch.float32)[order].contiguous()
-    rowptr = torch.zeros(m + 1, dtype=torch.int64, device=device)
-    rowptr[1:] = torch.cumsum(torch.bincount(row, minlength=m), 0)
     out = torch.empty((m, F + pad), dtype=torch.float32, device=device)
     if col.numel() == 0:
         col = torch.zeros(1, dtype=torch.int32, device=device)
@@ -60,12 +88,41 @@ def spmm(index, value, m, n, matrix):
 def generate_sign_features(x, edge_index, edge_weight, sign_k):
     """HashDataset._generate_sign_features (reference datasets/elph.py:87-110) for node features x [N, F].
     sign_k == 0: one propagation step.  sign_k > 0: [x, A x, A x, ...] -- the reference's loop multiplies `data.x`, not the
-    previous product, every time (datasets/elph.py:105-107); that behaviour is kept."""
+    previous product, every time (datasets/elph.py:105-107); that behaviour is kept (the product is computed once)."""
+    lib = _native.lib()
     n = x.size(0)
-    ei, w = gcn_norm(edge_index, edge_weight.float(), n)
+    device = _compute_device(x, edge_index)
+    home = x.device
+    xd = x.to(device=device, dtype=torch.float32).contiguous()
+    F = xd.size(1)
+    pad = (-F) % 4
+    if pad:
+        xd = torch.nn.functional.pad(xd, (0, pad))
+    row = edge_index[0].to(device).contiguous()
+    col = edge_index[1].to(device).contiguous()
+    w = edge_weight.to(device=device, dtype=torch.float32).contiguous()
+    if w.numel() == 0:  # (kernels never dereference an empty edge list, but the pointers must exist)
+        w = torch.zeros(1, dtype=torch.float32, device=device)
+    E = row.numel()
+    err = torch.zeros(1, dtype=torch.int32, device=device)
+    scan = torch.empty(lib.ss_gcn_scan_bytes(n), dtype=torch.uint8, device=device)  # first int32 word: some weight differs from 1
+    _native.check(lib.ss_gcn_scan_edges(_ptr(row), _ptr(col), _ptr(w), E, n, _ptr(scan), _stream(device)), 'ss_gcn_scan_edges')
+    # for the degrees: index_add over `col` in edge order -- the order only matters when some weight differs from 1
+    rowptr_c, order_c = group_ids_stable(col, n, err, only_if=scan)
+    rowptr_r, order_r = group_ids_stable(row, n, err)  # for the product: scatter-add over `row` in edge order
+    dinv = torch.empty(n, dtype=torch.float32, device=device)
+    loop_w = torch.empty(n, dtype=torch.float32, device=device)
+    out = torch.empty((n, F + pad), dtype=torch.float32, device=device)
+    if E == 0:
+        row = col = torch.zeros(1, dtype=torch.int64, device=device)
+    _native.check(lib.ss_gcn_degree(_ptr(rowptr_c), _ptr(order_c), _ptr(row), _ptr(w), n, _ptr(scan), _ptr(dinv), _ptr(loop_w), _stream(device)),
+                  'ss_gcn_degree')
+    _native.check(lib.ss_sign_spmm(_ptr(rowptr_r), _ptr(order_r), _ptr(col), _ptr(w), _ptr(dinv), _ptr(loop_w), _ptr(scan), n, _ptr(xd), F + pad, _ptr(out),
+                                   _stream(device)), 'ss_sign_spmm')
+    if int(err.item()):  # (the one host read of the chain)
+        raise IndexError('edge_index refers to nodes outside [0, num_nodes)')
+    ax = out[:, :F] if pad else out
+    ax = ax if home == device else ax.to(home)
     if sign_k == 0:
-        return spmm(ei, w, n, n, x)
-    xs = [x]
-    for _ in range(sign_k):
-        xs.append(spmm(ei, w, n, n, x))
-    return torch.cat(xs, dim=-1)
+        return ax
+    return torch.cat([x.to(torch.float32)] + [ax] * sign_k, dim=-1)

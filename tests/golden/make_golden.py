@@ -283,9 +283,17 @@ def load_reference_hash_dataset(nan_bias=False):
     gc = types.ModuleType('torch_geometric.nn.conv.gcn_conv')
 
     def gcn_norm(edge_index, edge_weight, num_nodes):
+        # torch_geometric.nn.conv.gcn_conv.gcn_norm with its defaults, RESTATED (the package is not in this image):
+        # add_remaining_self_loops(fill_value=1) -- existing self loops leave the list, every node gets one loop behind all other
+        # edges carrying its existing loop's weight (scatter assignment: the last one in edge order) or 1 --, deg = scatter_add
+        # of the weights over `col`, deg^-1/2 with inf -> 0, norm = dis[row] * w * dis[col]
+        row, col = edge_index[0], edge_index[1]
+        keep = row != col
+        loop_w = torch.ones(num_nodes)
+        loop_w[row[~keep]] = edge_weight[~keep]
         loops = torch.arange(num_nodes).repeat(2, 1)
-        ei = torch.cat([edge_index, loops], dim=1)
-        ew = torch.cat([edge_weight, torch.ones(num_nodes)])
+        ei = torch.cat([edge_index[:, keep], loops], dim=1)
+        ew = torch.cat([edge_weight[keep], loop_w])
         deg = torch.zeros(num_nodes).index_add_(0, ei[1], ew)
         dis = deg.pow(-0.5)
         dis[torch.isinf(dis)] = 0
@@ -367,6 +375,39 @@ def make_g14():
     _spi.IndexMixin._validate_indices = _orig_validate
     np.savez_compressed(os.path.join(HERE, 'g14_hash_dataset.npz'), **g)
     print('G14 written:', {k: v.shape for k, v in g.items() if k.endswith('subgraph_features')}, g['ba_fl0_zo1_files'])
+
+
+def make_g15():
+    """G15: the reference's OWN HashDataset._generate_sign_features (datasets/elph.py:87-110) for sign_k in {0, 2} under the
+    restated gcn_norm / spmm of load_reference_hash_dataset -- flagged "PyG semantics restated", exactly how A6 is pinned: it
+    pins the reference-owned part (the sign_k loop that re-multiplies data.x, the concatenation, the float() of the weights)
+    and the edge-order accumulation; the restatement itself waits for tools/export_pyg_fixture.py (G13).  Graphs: existing self
+    loops (one node with two of different weight: the last one counts), duplicate edges, isolated nodes, a hub row; unit and
+    non-integer weights (so that the ORDER of every fp32 sum matters); F = 12 (not a multiple of 4) and 64."""
+    ref_ds = load_reference_hash_dataset(False)
+    g = {}
+    rng = np.random.RandomState(15)
+    n, e = 300, 3000
+    ei = rng.randint(0, n - 5, size=(2, e)).astype(np.int64)          # the last five nodes are isolated
+    ei[:, :6] = np.array([[5, 5, 9, 11, 40, 40], [5, 5, 9, 11, 41, 41]])  # self loops (node 5 twice) and a duplicate edge
+    ei[1, 100:400] = 17                                                 # a hub column / row after the flip below
+    ei = np.concatenate([ei, ei[::-1]], axis=1)
+    g['edge_index'], g['num_nodes'] = ei, np.asarray(n)
+    weights = {'unit': np.ones(ei.shape[1], dtype=np.float32), 'float': (rng.random_sample(ei.shape[1]) * 3 + 0.1).astype(np.float32)}
+    for F in (12, 64):
+        x = rng.randn(n, F).astype(np.float32)
+        g[f'x_F{F}'] = x
+        for wname, w in weights.items():
+            g[f'w_{wname}'] = w
+            for k in (0, 2):
+                data = _Data(x=torch.from_numpy(x), num_nodes=n)
+                out = ref_ds.HashDataset._generate_sign_features(None, data, torch.from_numpy(ei), torch.from_numpy(w), k)
+                assert out.dtype == torch.float32 and out.shape == (n, F * (1 if k == 0 else k + 1))
+                g[f'sign_k{k}_F{F}_{wname}'] = out.numpy()
+    g['note'] = np.asarray('outputs of /root/reference/src/datasets/elph.py HashDataset._generate_sign_features; gcn_norm / torch_sparse.spmm '
+                           'are the restatements of tests/golden/make_golden.py (PyG and torch_sparse are not in this image)')
+    np.savez_compressed(os.path.join(HERE, 'g15_sign_features.npz'), **g)
+    print('G15 written:', sorted(k for k in g if k.startswith('sign_')))
 
 
 def args(h=2, p=8, P=128, floor_sf=False, use_zero_one=True):
@@ -595,8 +636,11 @@ if __name__ == '__main__':
         make_g12()
     elif '--only-g14' in sys.argv:
         make_g14()
+    elif '--only-g15' in sys.argv:
+        make_g15()
     else:
         main()
         make_g10()
         make_g12()
         make_g14()
+        make_g15()

@@ -253,6 +253,23 @@ def test_sign_feature_propagation_restatement():
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
 
 
+def test_sign_features_vs_the_references_own_function():
+    """G15 = outputs of the reference's OWN HashDataset._generate_sign_features (datasets/elph.py:87-110; made by
+    tests/golden/make_golden.py --only-g15) for sign_k in {0, 2}, unit and non-integer weights, F = 12 / 64, on a graph with
+    existing self loops, duplicate edges, isolated nodes and a hub -- under the RESTATED gcn_norm / torch_sparse.spmm (PyG and
+    torch_sparse are not in this image: "PyG semantics restated", as for A6).  Pins the reference-owned part -- the sign_k loop
+    that re-multiplies data.x, the concatenation -- and the edge-order accumulation of both sums: bit-exact."""
+    g = load_golden('g15_sign_features.npz')
+    n = int(g['num_nodes'])
+    for F in (12, 64):
+        for wname in ('unit', 'float'):
+            for k in (0, 2):
+                got = oracle.generate_sign_features(g[f'x_F{F}'], g['edge_index'], g[f'w_{wname}'], k)
+                want = g[f'sign_k{k}_F{F}_{wname}']
+                assert got.shape == want.shape == (n, F * (1 if k == 0 else k + 1))
+                assert np.array_equal(got, want), (F, wname, k, float(np.abs(got - want).max()))
+
+
 def test_estimate_bias_entry_point_matches_the_hll_count_branch(regenerated_tables):
     """so_estimate_bias (the stand-alone _estimate_bias / _refine_hll_count_estimate) against golden G5's values"""
     prm = oracle_params(regenerated_tables[8])
