@@ -237,6 +237,8 @@ int ss_group_links_by_source(const int64_t *links, int64_t B, int64_t N, int32_t
  * 21 GB): out_links[t] := links[order[t]] (int64 [n, 2]) before, out[order[t], :] := rows[t, :] (float [n, width]) after a
  * ss_pair_features_grouped(order = NULL) over the gathered chunk -- walking `order` inside the query would make every pair
  * read and write at random places of those arrays from inside its latency chain. */
+/* (links and out_links must be 16-byte aligned -- a pair moves as one vector --: SS_ERR_INVALID_ARG otherwise.  `order` entries are
+ * NOT validated by any of these calls: each must lie in [0, n) of the array it indexes, as ss_group_links_by_source produces them) */
 int ss_gather_links(const int64_t *links, const int32_t *order, int64_t n, int64_t *out_links, void *stream);
 int ss_scatter_feature_rows(const float *rows, const int32_t *order, int64_t n, int32_t width, float *out, void *stream);
 int ss_pair_features_grouped(const int64_t *links, const int32_t *order, int64_t B, int64_t N, int32_t h,

@@ -689,6 +689,8 @@ extern "C" int ss_gather_links(const int64_t *links, const int32_t *order, int64
 {
     if (n < 0 || (n > 0 && (!links || !order || !out_links))) return SS_ERR_INVALID_ARG;
     if (n == 0) return SS_OK;
+    // the kernel moves a pair as ONE 16-byte vector: both arrays must be 16-byte aligned (rows of a torch int64 [n, 2] tensor are)
+    if ((reinterpret_cast<uintptr_t>(links) | reinterpret_cast<uintptr_t>(out_links)) & 15) return SS_ERR_INVALID_ARG;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(ss::gather_links_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, links, order, n, out_links);
@@ -734,6 +736,7 @@ static int pair_features_grouped_impl(int which /* -1: chosen per hop count, 0: 
         return pair_features_impl(links, B, N, h, mh, P, hll, cards, cards_stride, prm, flags, degrees, out, nullptr, nullptr, nullptr,
                                   err_flag, stream, order, /*grouped=*/true);
     }
+    if (order && B >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;  // (order entries are int32 pair indices, as on the other path)
     PairTables tabs = {};
     for (int k = 0; k < h; ++k) {
         if (!mh[k] || !hll[k]) return SS_ERR_INVALID_ARG;

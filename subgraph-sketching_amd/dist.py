@@ -211,20 +211,52 @@ class PeerShard(RowShard):
                 opened = [rebuild(*args) for rebuild, args in everyone[r]]
                 for t in opened:
                     if t.device != self.device:  # another GPU of the node: this GPU must be allowed to address its memory
+                        # asked BEFORE anything touches the mapping: a kernel (or copy) that stores through a mapping its GPU
+                        # cannot address faults the whole process (hipDeviceCanAccessPeer)
+                        if not torch.cuda.can_device_access_peer(self.device.index or 0, t.device.index or 0):
+                            raise RuntimeError(f'{self.device} cannot address the memory of {t.device} (no peer access)')
                         _enable_peer_access(self.device, t.device)
                 self._peer_tensors[r] = opened
         except Exception as exc:  # (mapping a peer's memory can fail on ONE rank only: agree before anybody waits for anybody)
             failure = exc
-        ok = torch.tensor([0.0 if failure else 1.0], device=device if self.native else 'cpu')
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if float(ok.item()) < 1.0:
-            raise RuntimeError(f'peer-write build: a rank could not map its peers\' tables (this rank: {failure!r})')
+        self._agree(failure, 'a rank could not map its peers\' tables')
         self._order = [r for r in range(self.world) if r != self.rank]
-        self.hop_barrier()  # nobody starts storing into a table before everybody has mapped it
+        # store-and-read-back probe through every mirror: rank r writes r + 1 into row r of every PEER's cards table (column 0), a
+        # barrier, then every rank checks the rows its peers wrote -- a mapping that opened but does not reach the peer's memory
+        # is found here, on every rank or on none, not inside a kernel of the first build
+        failure = None
+        try:
+            for r in self._order:
+                self._peer_tensors[r][2 * max_hops][self.rank, 0] = float(self.rank + 1)
+            self.cards[self.rank, 0] = float(self.rank + 1)
+            self.hop_barrier()
+            got = self.cards[:self.world, 0].cpu()
+            want = torch.arange(1, self.world + 1, dtype=torch.float32)
+            if not torch.equal(got, want):
+                raise RuntimeError(f'probe stores of the peers did not arrive: rows {got.tolist()} (want {want.tolist()})')
+        except Exception as exc:
+            failure = exc
+        self._agree(failure, 'the store-and-read-back probe through the mirrors failed')
+        self.generation = 0
+        self.hop_barrier()  # nobody starts storing into a table before everybody has mapped (and probed) it
+
+    def _agree(self, failure, what):
+        """all ranks raise, or none (a rank that failed alone would leave the others waiting in a collective)"""
+        ok = torch.tensor([0.0 if failure else 1.0], device=self.device if self.native else 'cpu')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if float(ok.item()) < 1.0:
+            raise RuntimeError(f'peer-write build: {what} (this rank: {failure!r})')
 
     def tables(self, max_hops, num_perm, m, device):
+        """the shard's buffers for ONE build.  They are shared with every rank, and every rank's kernels of the new build store into
+        them: a cross-rank barrier first, in stream order -- whatever this rank (or a lagging peer) still has queued on the tables
+        of the PREVIOUS build through this shard (a query, a copy) completes before anybody's first store of the new one
+        (a rank still reading the old rows would otherwise see them change under it).  `generation` counts the builds:
+        views handed out by an earlier build are stale once it moves."""
         if (max_hops, num_perm, m) != self.shape or torch.device(device) != self.device:
             raise ValueError(f'this shard was made for {self.shape} on {self.device}')
+        self.hop_barrier()
+        self.generation += 1
         return self.mh, self.hll, self.cards
 
     def mirrors(self, kind, k):
@@ -261,15 +293,24 @@ def _enable_peer_access(device, other):
     torch.cuda.synchronize(device)
 
 
-def peer_write_build_hash_tables(eh, num_nodes, edge_index, shard=None, group=None):
+def peer_write_build_hash_tables(eh, num_nodes, edge_index, shard=None, group=None, fallback=False):
     """`eh.build_hash_tables` with the rows of every hop computed once across the group and written straight into every rank's
-    tables (PeerShard).  Pass the shard of an earlier call to reuse its IPC-shared buffers; returns (table, cards, shard)."""
+    tables (PeerShard).  Pass the shard of an earlier call to reuse its IPC-shared buffers (the tables of that earlier build are
+    overwritten: they are the same memory); returns (table, cards, shard).  fallback=True: if the ranks cannot map or reach each
+    other's tables (PeerShard's constructor fails on every rank or on none), the exchange form (RowShard) builds instead and
+    `shard` comes back as None."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         table, cards = eh.build_hash_tables(num_nodes, edge_index)
         return table, cards, None
     if shard is None:
         device = edge_index.device if edge_index.is_cuda else torch.device('cuda', torch.cuda.current_device())
-        shard = PeerShard(num_nodes, eh.max_hops, eh.num_perm, eh.m, device, group)
+        try:
+            shard = PeerShard(num_nodes, eh.max_hops, eh.num_perm, eh.m, device, group)
+        except RuntimeError:
+            if not fallback:
+                raise
+            table, cards = sharded_build_hash_tables(eh, num_nodes, edge_index, group)
+            return table, cards, None
     table, cards = eh._build(num_nodes, edge_index, shard)
     return table, cards, shard
 

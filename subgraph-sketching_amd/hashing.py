@@ -886,6 +886,7 @@ class ElphHashes(object):
     # and batched tail walks it wins there too (3.70 against 3.92 ms), so there is no cap any more.  SS_FUSED_STAGE_MAX_MB:
     # measurement hook
     FUSED_STAGE_MAX_TABLE_BYTES = int(os.environ.get('SS_FUSED_STAGE_MAX_MB', str(1 << 30))) << 20
+    HUB_HINT_SHAPES = 256  # graph shapes that get a hub hint word (one pinned int32 each, kept for the engine's lifetime)
 
     def __init__(self, args, fuse_hop_stage=None, defer_first_hop=None, defer_table_hop=None):
         """args: the reference's namespace (max_hash_hops, floor_sf, minhash_num_perm, hll_p, use_zero_one).  Extensions (keyword
@@ -935,14 +936,14 @@ class ElphHashes(object):
         self.group_links = 'auto'
         # skip the hub-pass launches of build_hash_tables for shapes whose earlier builds listed no hub rows (see _hub_hint)
         self.hub_hints = os.environ.get('SS_HUB_HINTS', '1') != '0'
-        self._hub_words = {}
+        self._hub_words, self._hub_arena = {}, None
 
     # no device handles in pickled state (SURVEY.md section 8(b) threading row)
     def __getstate__(self):
         state = dict(self.__dict__)
         state['_dev_params'], state['_dev_perms'] = {}, {}
         state['_csr_cache'], state['_deferred'] = None, None
-        state['_hub_words'] = {}
+        state['_hub_words'], state['_hub_arena'] = {}, None
         state.pop('_tables_id', None)
         state['minhash_prop'], state['hll_prop'] = None, None
         return state
@@ -951,7 +952,7 @@ class ElphHashes(object):
         self.__dict__.update(state)
         self.__dict__.setdefault('hub_hints', os.environ.get('SS_HUB_HINTS', '1') != '0')
         self.__dict__.setdefault('group_links', 'auto')
-        self._hub_words = {}
+        self._hub_words, self._hub_arena = {}, None
         self._deferred = _DeferredErrors()
         self._csr_cache = _CsrCache(self._bounds, self._prop_hub_hint)
         self.minhash_prop = MinhashPropagation(self._csr_cache, self._report_after_host_copy, self.__dict__.get('_defer_first_hop'),
@@ -1073,9 +1074,14 @@ class ElphHashes(object):
         key = (str(device), int(num_nodes), tuple(edge_index.shape), HUB_THRESHOLD)
         word = self._hub_words.get(key)
         if word is None:
-            if len(self._hub_words) >= 16:
-                self._hub_words.pop(next(iter(self._hub_words)))
-            word = self._hub_words[key] = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+            # One pinned arena for the engine's lifetime, one word per shape, NEVER handed back while the engine lives: a first-hop
+            # launch still in flight stores into its word (system-scope store, csrc report_hub_rows) -- a word returned to torch's
+            # pinned-memory cache could be given to somebody else by then.  More shapes than words: no hint for them.
+            if self._hub_arena is None:
+                self._hub_arena = torch.full((self.HUB_HINT_SHAPES,), -1, dtype=torch.int32).pin_memory()
+            if len(self._hub_words) >= self.HUB_HINT_SHAPES:
+                return None, False
+            word = self._hub_words[key] = self._hub_arena[len(self._hub_words):len(self._hub_words) + 1]
         return word, int(word[0]) == 0
 
     def check_errors(self):
