@@ -35,6 +35,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = '/root/reference/src/hashing.py'
 TABLES = os.path.join(REPO, 'subgraph-sketching_amd', 'data', 'hllpp_tables_regenerated.npz')
+# tools/import_external_fixtures.sh: the same vectors with datasketch's REAL tables (SS_GOLDEN_TABLES = the file written by
+# tools/export_datasketch_fixture.py) into another directory (SS_GOLDEN_OUT), to be compared with the committed ones
+EXPORTED_TABLES = os.environ.get('SS_GOLDEN_TABLES')
+OUT = os.environ.get('SS_GOLDEN_OUT', HERE)
 
 
 def _alpha(p):
@@ -42,8 +46,23 @@ def _alpha(p):
     return {4: 0.673, 5: 0.697, 6: 0.709}.get(p, 0.7213 / (1.0 + 1.079 / m))
 
 
+def _load_tables():
+    """{'p_min', 'p_max', 'thresholds' [15], 'raw_p<p>', 'bias_p<p>', 'alpha' {p: value} or None}: the regenerated tables this
+    repository ships, or datasketch's own as exported by tools/export_datasketch_fixture.py (SS_GOLDEN_TABLES)"""
+    if not EXPORTED_TABLES:
+        tz = np.load(TABLES)
+        return {**{k: tz[k] for k in tz.files}, 'alpha': None}
+    ez = np.load(EXPORTED_TABLES)
+    ps = [int(p) for p in ez['p_list']]
+    out = {'p_min': min(ps), 'p_max': max(ps), 'alpha': {p: float(ez[f'alpha_p{p}']) for p in ps},
+           'thresholds': np.asarray([float(ez[f'threshold_p{p}']) if p in ps else 0.0 for p in range(4, 19)])}
+    for p in ps:
+        out[f'raw_p{p}'], out[f'bias_p{p}'] = ez[f'raw_p{p}'], ez[f'bias_p{p}']
+    return out
+
+
 def install_shims(nan_bias=False):
-    tz = np.load(TABLES)
+    tz = _load_tables()
     pmin, pmax = int(tz['p_min']), int(tz['p_max'])
 
     class MessagePassing(torch.nn.Module):
@@ -78,7 +97,7 @@ def install_shims(nan_bias=False):
         def __init__(self, p=8):
             self.p = p
             self.m = 1 << p
-            self.alpha = _alpha(p)
+            self.alpha = tz['alpha'][p] if tz['alpha'] else _alpha(p)
             self.max_rank = 64 - p
             self.reg = np.zeros(self.m, dtype=np.int8)
             self.hashfunc = None
@@ -180,7 +199,7 @@ def make_g10():
         Au = ssp.csr_matrix((np.ones(src.size, dtype=int), (src, dst)), shape=(n, n))  # edge_weight = ones (datasets/elph.py:62)
         g['RA_unit_weights'] = H.RA(Au, lk, batch_size=1000)[0].numpy()
     assert g['RA'].dtype == np.float32 and np.isfinite(g['RA']).all() and (g['CN'] > 0).sum() > 100
-    np.savez_compressed(os.path.join(HERE, 'g10_heuristics.npz'), **g)
+    np.savez_compressed(os.path.join(OUT, 'g10_heuristics.npz'), **g)
     print('G10 written')
 
 
@@ -251,7 +270,7 @@ def make_g12():
                 g[f'uni_sha_hll_{k}'] = np.asarray(sha(table[k]['hll'].numpy().astype(np.uint8)))
                 g[f'uni_sha_mh_{k}'] = np.asarray(sha(table[k]['minhash'].numpy().astype(np.uint32)))
         assert table[1]['minhash'].dtype == torch.int64 and table[1]['hll'].dtype == torch.int8 and cards.dtype == torch.float32
-    np.savez_compressed(os.path.join(HERE, 'g12_elph_forward.npz'), **g)
+    np.savez_compressed(os.path.join(OUT, 'g12_elph_forward.npz'), **g)
     print('G12 written')
 
 
@@ -373,7 +392,7 @@ def make_g14():
                     g[f'{tag}_RA'] = ds.RA.numpy()
                     g[f'{tag}_labels'] = np.asarray(ds.labels)
     _spi.IndexMixin._validate_indices = _orig_validate
-    np.savez_compressed(os.path.join(HERE, 'g14_hash_dataset.npz'), **g)
+    np.savez_compressed(os.path.join(OUT, 'g14_hash_dataset.npz'), **g)
     print('G14 written:', {k: v.shape for k, v in g.items() if k.endswith('subgraph_features')}, g['ba_fl0_zo1_files'])
 
 
@@ -406,7 +425,7 @@ def make_g15():
                 g[f'sign_k{k}_F{F}_{wname}'] = out.numpy()
     g['note'] = np.asarray('outputs of /root/reference/src/datasets/elph.py HashDataset._generate_sign_features; gcn_norm / torch_sparse.spmm '
                            'are the restatements of tests/golden/make_golden.py (PyG and torch_sparse are not in this image)')
-    np.savez_compressed(os.path.join(HERE, 'g15_sign_features.npz'), **g)
+    np.savez_compressed(os.path.join(OUT, 'g15_sign_features.npz'), **g)
     print('G15 written:', sorted(k for k in g if k.startswith('sign_')))
 
 
@@ -474,7 +493,7 @@ def main():
     g['init_mh_P128_tail'] = ref.ElphHashes(args()).initialise_minhash(100000).numpy()[-16:].astype(np.uint32)
     g['init_hll_p8_tail_idx'] = np.argmax(ref.ElphHashes(args()).initialise_hll(100000).numpy()[-64:], axis=1)
     g['init_hll_p8_tail_val'] = np.max(ref.ElphHashes(args()).initialise_hll(100000).numpy()[-64:], axis=1)
-    np.savez_compressed(os.path.join(HERE, 'g1_g2_init.npz'), **g)
+    np.savez_compressed(os.path.join(OUT, 'g1_g2_init.npz'), **g)
 
     # ---- G3/G4: small BA graph, full tables + features -------------------------------------
     g = {}
@@ -510,11 +529,11 @@ def main():
                                                                    cards[:, :2], batch_size=7).numpy()
     g['feat_h2_1d'] = ref.ElphHashes(a).get_subgraph_features(links[0], {k: tables[k] for k in range(3)},
                                                               cards[:, :2]).numpy()
-    np.savez_compressed(os.path.join(HERE, 'g3_g4_ba40.npz'), **g)
+    np.savez_compressed(os.path.join(OUT, 'g3_g4_ba40.npz'), **g)
     # the reference's own on-disk cache format (datasets/elph.py:200-204: torch.save of the hashes dict and of cards),
     # written by the reference's objects themselves: the --load_hashes compatibility fixture
-    torch.save({k: tables[k] for k in range(3)}, os.path.join(HERE, 'ref_ba40_hashcache.pt'))
-    torch.save(cards[:, :2].clone(), os.path.join(HERE, 'ref_ba40_cardcache.pt'))
+    torch.save({k: tables[k] for k in range(3)}, os.path.join(OUT, 'ref_ba40_hashcache.pt'))
+    torch.save(cards[:, :2].clone(), os.path.join(OUT, 'ref_ba40_cardcache.pt'))
 
     # ---- G9: BUDDY's degree-normalised copy (models/elph.py:276-293), computed by the reference's own method -----------
     buddy = load_reference_buddy()
@@ -525,7 +544,7 @@ def main():
         sf = torch.from_numpy(g[f'feat_h{h}_zo1_fl0'])
         d = torch.from_numpy(deg)
         g9[f'normed_h{h}'] = buddy._append_degree_normalised(None, sf, d[links[:, 0]], d[links[:, 1]]).numpy()
-    np.savez_compressed(os.path.join(HERE, 'g9_degree_normalised.npz'), **g9)
+    np.savez_compressed(os.path.join(OUT, 'g9_degree_normalised.npz'), **g9)
 
     # ---- G3b: other (p, P) parameterisations on the same graph ------------------------------
     g = {'edge_index': ei, 'num_nodes': np.asarray(n), 'links': links.numpy()}
@@ -539,7 +558,7 @@ def main():
         g[f'p{p}P{P}_cards_uses_tables'] = torch.isnan(cdn).numpy()
         g[f'p{p}P{P}_feat'] = e.get_subgraph_features(links, tb, cd).numpy()
         g[f'p{p}P{P}_feat_uses_tables'] = torch.isnan(en.get_subgraph_features(links, tb, cdn)).numpy()
-    np.savez_compressed(os.path.join(HERE, 'g3b_params.npz'), **g)
+    np.savez_compressed(os.path.join(OUT, 'g3b_params.npz'), **g)
 
     # ---- G5: hll_count known answers ------------------------------------------------------------
     g = {}
@@ -565,7 +584,7 @@ def main():
     g['count_uses_tables'] = torch.isnan(ehn.hll_count(regs)).numpy()
     g['count_1d'] = eh.hll_count(regs[1]).numpy()
     g['count_int64'] = eh.hll_count(regs.long()).numpy()
-    np.savez_compressed(os.path.join(HERE, 'g5_hll_count.npz'), **g)
+    np.savez_compressed(os.path.join(OUT, 'g5_hll_count.npz'), **g)
 
     # ---- G7: edge cases ----------------------------------------------------------------------------
     g = {}
@@ -580,7 +599,7 @@ def main():
     lk = torch.tensor([[0, 1], [9, 10], [11, 0], [5, 6], [6, 5], [7, 7]])
     g['links'] = lk.numpy()
     g['feat'] = e.get_subgraph_features(lk, tb, cd).numpy()
-    np.savez_compressed(os.path.join(HERE, 'g7_edge_cases.npz'), **g)
+    np.savez_compressed(os.path.join(OUT, 'g7_edge_cases.npz'), **g)
 
     # ---- G8: medium graph reaching every estimator branch -----------------------------------------
     g = {}
@@ -607,7 +626,7 @@ def main():
         g[f'feat_h{h}'] = ref.ElphHashes(a).get_subgraph_features(lk, sub, cd[:, :h]).numpy()
         g[f'feat_h{h}_uses_tables'] = torch.isnan(
             refnan.ElphHashes(a).get_subgraph_features(lk, sub, cdn[:, :h])).numpy()
-    np.savez_compressed(os.path.join(HERE, 'g8_uniform3000.npz'), **g)
+    np.savez_compressed(os.path.join(OUT, 'g8_uniform3000.npz'), **g)
 
     # ---- G6: digests of a collab-scale build --------------------------------------------------------
     if '--big' in sys.argv:
@@ -625,8 +644,8 @@ def main():
         g['cards_sha_table_independent'] = np.asarray(sha(torch.where(keep, cd, torch.zeros_like(cd)).numpy()))
         g['cards_sample'] = cd[:4096].numpy()
         g['cards_sample_uses_tables'] = torch.isnan(cdn[:4096]).numpy()
-        np.savez_compressed(os.path.join(HERE, 'g6_collab_scale_digests.npz'), **g)
-    print('golden vectors written to', HERE)
+        np.savez_compressed(os.path.join(OUT, 'g6_collab_scale_digests.npz'), **g)
+    print('golden vectors written to', OUT)
 
 
 if __name__ == '__main__':
