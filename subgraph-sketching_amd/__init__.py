@@ -6,7 +6,7 @@ hyphenated name).  Public surface = the reference's src/hashing.py surface.
 from .hashing import (LABEL_LOOKUP, ElphHashes, HllPropagation, HopSketch, MinhashPropagation, SketchTable,
                       build_csr, load_sketches, pack_minhash, save_sketches, unpack_minhash)
 from .feature_store import DeviceFeatureStore
-from . import _native, hll_tables, dist, heuristics, sign, roofline
+from . import _native, hll_tables, knobs, dist, heuristics, sign, roofline
 
 __all__ = ['LABEL_LOOKUP', 'ElphHashes', 'HllPropagation', 'MinhashPropagation', 'SketchTable', 'HopSketch',
-           'build_csr', 'DeviceFeatureStore', 'pack_minhash', 'unpack_minhash', 'save_sketches', 'load_sketches', 'hll_tables', 'dist', 'heuristics', 'sign', 'roofline']
+           'build_csr', 'DeviceFeatureStore', 'pack_minhash', 'unpack_minhash', 'save_sketches', 'load_sketches', 'hll_tables', 'knobs', 'dist', 'heuristics', 'sign', 'roofline']

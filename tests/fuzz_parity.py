@@ -16,7 +16,7 @@ from oracle import oracle
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 dev = torch.device('cuda:0')
-H = ssa.hashing
+H = ssa.knobs
 t8 = ssa.hll_tables.load(8, prefer='regenerated')
 prm8 = oracle.HllParams(t8.p, t8.threshold, t8.raw_estimate, t8.bias, alpha=t8.alpha, lc_table=H.linear_counting_table(256).numpy())
 rng = np.random.RandomState(int(os.environ.get('FUZZ_SEED', '12345')))
