@@ -16,7 +16,8 @@ from oracle import oracle
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 dev = torch.device('cuda:0')
-H = ssa.knobs
+H = ssa.hashing
+K = ssa.knobs  # (the switches live there; hashing.<NAME> only reads them)
 t8 = ssa.hll_tables.load(8, prefer='regenerated')
 prm8 = oracle.HllParams(t8.p, t8.threshold, t8.raw_estimate, t8.bias, alpha=t8.alpha, lc_table=H.linear_counting_table(256).numpy())
 rng = np.random.RandomState(int(os.environ.get('FUZZ_SEED', '12345')))
@@ -34,7 +35,7 @@ while time.time() - t0 < seconds:
     if rng.randint(4) == 0:
         e = e[:, e.max(axis=0) < n - 5] if e.shape[1] else e  # trailing nodes without a self loop
     ei = np.concatenate([e, e[::-1]], axis=1).astype(np.int64)
-    H.HUB_THRESHOLD = int(rng.choice([0, 0, 8, 40, 300])) or None
+    K.HUB_THRESHOLD = int(rng.choice([0, 0, 8, 40, 300])) or None
     B = int(rng.choice([1, 17, 400, 5000]))
     links = rng.randint(-n, n, size=(B, 2)).astype(np.int64)
     style = int(rng.randint(4))  # link lists with locality: the grouped / run-aware query paths (round 3)
@@ -42,8 +43,8 @@ while time.time() - t0 < seconds:
         links = links[np.argsort(links[:, 0], kind='stable')]
     elif style == 2:  # evaluation style: every source lists its pairs together
         links[:, 0] = np.repeat(rng.randint(-n, n, size=B // 7 + 1), 7)[:B]
-    H.GROUP_LINKS_MIN = int(rng.choice([1, 1, 1 << 20]))          # 1: every query of this trial takes the grouped path
-    H.GROUP_GATHER_MIN = int(rng.choice([1, 1 << 24]))            # 1: ... through the gather / scatter passes
+    K.GROUP_LINKS_MIN = int(rng.choice([1, 1, 1 << 20]))          # 1: every query of this trial takes the grouped path
+    K.GROUP_GATHER_MIN = int(rng.choice([1, 1 << 24]))            # 1: ... through the gather / scatter passes
     # a quarter of the trials: other sketch sizes (the run-time-sized kernels, the other specialised permutation counts)
     P, hp = (int(rng.choice([4, 20, 64, 100, 192, 256, 260])), int(rng.choice([4, 5, 6, 8, 10, 12]))) if rng.randint(4) == 0 else (128, 8)
     tp = t8 if hp == 8 else ssa.hll_tables.load(hp, prefer='regenerated')
