@@ -171,6 +171,11 @@ def roofline_numbers(rf, bytes_alg, launch_ms, table_bytes, traffic):
             'ceiling_note': 'random 512-byte-row gathers from a table of this size, tools/micro/gather_ceiling.hip (profiles/round4_gather_ceiling.txt)'}
 
 
+# the rows above the hub threshold are walked as hub units by leading workgroups of the row launches (csrc/ss_hub.hpp); SS_HUB_LAUNCHES=1
+# brings back the launches of their own of rounds 1-3 -- the byte model follows (roofline.kernel_bytes `hosted`)
+HUB_UNITS_HOSTED = os.environ.get('SS_HUB_LAUNCHES', '0') in ('', '0')
+
+
 def hub_stats(ssa, ei_np, n):
     """(hub_edges, hub_rows) under the hub threshold a build of this graph uses: the rows the row kernels leave to the hub passes"""
     thr = ssa.hashing.HUB_THRESHOLD if ssa.hashing.HUB_THRESHOLD is not None else ssa.hashing.default_hub_threshold(ei_np.shape[1])
@@ -239,7 +244,7 @@ def secondary_case(ssa, dev, name, config, graph='uniform', alpha=0.5, api='buil
     lib.ss_profile_enable(0)
     eh.check_errors()
     per_launch = links.size(0) if api == 'buddy' and links.size(0) <= 11000000 else batch
-    bytes_ = rf.kernel_bytes(n, e_dir + (n if api == 'elph' else 0), P, HLL_P, h, per_launch, hub_e, hub_n)[family]
+    bytes_ = rf.kernel_bytes(n, e_dir + (n if api == 'elph' else 0), P, HLL_P, h, per_launch, hub_e, hub_n, HUB_UNITS_HOSTED)[family]
     survey = None
     H = ssa.hashing
     if api == 'buddy' and H.GROUP_LINKS_MIN and links.size(0) >= H.GROUP_LINKS_MIN and links.size(0) <= 11000000:
@@ -537,7 +542,7 @@ def main():
             step()
         fence()
         lib.ss_profile_enable(0)
-        model = rf.kernel_bytes(n, e_dir, P, HLL_P, h, min(links.size(0), batch), hub_e, hub_n)
+        model = rf.kernel_bytes(n, e_dir, P, HLL_P, h, min(links.size(0), batch), hub_e, hub_n, HUB_UNITS_HOSTED)
         model['hub_passes'] = (model['hub_first_hop'] + (h - 1) * model['hub_table_hop']) // h  # mean over the h launches of a step
         model['minhash_hop_rows'] = rf.minhash_rows_bytes(n, e_dir, 2 * min(links.size(0), batch), P)
         kernel_table = {}
@@ -558,14 +563,15 @@ def main():
                         row['bytes_basis'] = 'fabric bytes of the PMC passes'
             kernel_table[name] = row
         kernel_table['note'] = ('HIP-event brackets inside the library on the launch stream (include ~5 us of dispatch each); csr_build '
-                                'spans all launches of one build; hub_passes = the hub / mega-row launches of every hop')
+                                'spans all launches of one build; hub units (rows above the hub threshold) are hosted by the first_hop_hll and minhash_hop launches, '
+                                'whose bytes include them (hub_passes: their own launches, SS_HUB_LAUNCHES=1 only)')
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------------------------
     dom_family = {nat.PROF_FUSED: 'fused_first_hop_hll_hop', nat.PROF_PAIRS: 'pair_features'}.get(dom_tag, 'minhash_hop')
-    prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch, hub_e, hub_n)['minhash_hop']
+    prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch, hub_e, hub_n, HUB_UNITS_HOSTED)['minhash_hop']
     roof_kernel = "ss::propagate_kernel<128,256> (MinHash table hop: (E'+N)*4P + 4E + 8(N+1) bytes)"
     if dom_tag == nat.PROF_FUSED:
-        prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch, hub_e, hub_n)['fused_first_hop_hll_hop']
+        prop_bytes = rf.kernel_bytes(n, e_dir, P, HLL_P, h, batch, hub_e, hub_n, HUB_UNITS_HOSTED)['fused_first_hop_hll_hop']
         roof_kernel = ("ss::fused_hop_persistent_kernel<2> (MinHash first hop + HLL table hop: 4E + 8(N+1) + N*4P + (E'+N)*M + 4N bytes; "
                        "VALU-bound first hop over the memory-bound table hop)")
     if dom_tag == nat.PROF_PAIRS:

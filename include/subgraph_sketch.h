@@ -127,9 +127,10 @@ typedef struct ss_csr_graph {
  * two-level counting sort (LDS histograms per edge slice -> bucket offsets -> per-bucket LDS sort). */
 #define SS_MEGA_SLICE 1024      /* neighbours per slice of a mega row (one 64-neighbour chunk per wavefront of a hub workgroup) */
 #define SS_MEGA_SLOT_BYTES 1280 /* scratch per slice: partial MinHash row (<= 256 x u32) + partial HLL row (256 B) */
+#define SS_MEGA_DESC_WORDS 8   /* int32 words per entry of mega_rows: {row, first slice, slices, ticket (MinHash side), ticket (HLL side), 0, 0, 0} */
 size_t ss_csr_workspace_bytes(int64_t N, int64_t E);
 /* mega_rows / mega_count (nullable together): rows with more than max(hub_threshold, SS_MEGA_SLICE) in-edges are listed
- * there instead of in hub_rows: mega_rows must hold 4 * (E / SS_MEGA_SLICE + 1) int32, mega_count 2 int32; the slices of
+ * there instead of in hub_rows: mega_rows must hold SS_MEGA_DESC_WORDS * (E / SS_MEGA_SLICE + 1) int32, mega_count 2 int32; the slices of
  * all mega rows number at most 3 * (E / SS_MEGA_SLICE + 1) -- the scratch ss_csr_graph.mega_scratch needs SS_MEGA_SLOT_BYTES for each. */
 int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                  int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,

@@ -26,11 +26,14 @@ extern "C" {
 #define SS_PROF_FIRST_HOP_HLL 3   /* ss::hll_first_hop_kernel                                                            */
 #define SS_PROF_PAIRS 4           /* ss::pair_features_kernel                                                            */
 #define SS_PROF_CSR 5             /* all launches of one ss_csr_build                                                    */
-#define SS_PROF_HUB 6             /* hub / mega-row passes (propagate_hub_kernel, first_hop_hub_kernel)                  */
+#define SS_PROF_HUB 6             /* hub units as launches of their own (propagate_hub_kernel, first_hop_hub_kernel)     */
 #define SS_PROF_FUSED 7           /* ss::fused_hop_persistent_kernel (MinHash first hop + HLL table hop in one launch)     */
 #define SS_PROF_MINHASH_ROWS 8    /* ss_minhash_hop_rows: the MinHash table hop of a list of rows                          */
 #define SS_PROF_TAGS 9
 int ss_profile_enable(uint32_t tag_mask);   /* bit t enables family t; 0 disables everything */
+/* Library calls since the last reset that were given hub lists and served hub units -- hosted by their row launches (which leave no
+ * SS_PROF_HUB span) or as launches of their own; reset != 0 returns the count and clears it.  For the tests of the hub hints. */
+int64_t ss_debug_hub_calls(int32_t reset);
 int ss_profile_read(int32_t tag, float *mean_ms_out, int32_t *launches_out);
 
 /* Launch-duration probe for bench.py: records HIP events around `reps` back-to-back launches of the

@@ -128,7 +128,7 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None, err
     # counters + one scratch slot per slice (a row has > MEGA_SLICE edges, so there are at most E / MEGA_SLICE of them and
     # at most three times as many slices)
     max_mega = E // _native.MEGA_SLICE + 1
-    mega_rows = torch.empty((max_mega, 4), dtype=torch.int32, device=device)
+    mega_rows = torch.empty((max_mega, _native.MEGA_DESC_WORDS), dtype=torch.int32, device=device)
     mega_scratch = torch.empty(3 * max_mega * _native.MEGA_SLOT_BYTES, dtype=torch.uint8, device=device)
     ws_bytes = lib.ss_csr_workspace_bytes(num_nodes, E)
     if ws_bytes == 0:

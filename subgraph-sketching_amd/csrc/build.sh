@@ -12,7 +12,7 @@ mkdir -p build
 for f in $UNITS; do
   stale=0
   [ -f build/$f.o ] || stale=1
-  for dep in $f.hip ss_common.hpp ss_walks.hpp ../../include/subgraph_sketch.h ../../include/subgraph_sketch_debug.h build.sh; do
+  for dep in $f.hip ss_common.hpp ss_walks.hpp ss_hub.hpp ../../include/subgraph_sketch.h ../../include/subgraph_sketch_debug.h build.sh; do
     [ -e $dep ] && [ $dep -nt build/$f.o ] && stale=1
   done
   if [ $stale = 1 ]; then

@@ -189,6 +189,11 @@ __device__ __forceinline__ float hll_estimate(const EstimatorTables &t, int zero
     return e;
 }
 
+// 5 * 2^p as a float assembled from integer (scalar) arithmetic: 1.25 * 2^(p + 2).  `5.0f * (float)(1 << p)` is a VALU multiply, and its
+// wave-uniform result then occupies a VECTOR register for the whole kernel -- in kernels that sit at their register budget that
+// one register was spilled to scratch (round 4)
+__device__ __forceinline__ float five_times_two_to(int p) { return __uint_as_float(((uint32_t)(129 + p) << 23) | 0x200000u); }
+
 // cooperative staging of the estimator tables into LDS (all threads of the block call this)
 constexpr int kLcLdsMax = 1025;  // lc table staged in LDS when m + 1 <= kLcLdsMax (p <= 10)
 struct EstimatorLds {
@@ -215,7 +220,7 @@ __device__ __forceinline__ EstimatorTables stage_tables(EstimatorLds &lds, const
     t.n_tbl = prm.n_tbl;
     t.lc_min_zeros = prm.lc_min_zeros;
     t.alpha_mm = prm.alpha_mm;
-    t.five_m = 5.0f * (float)(1 << prm.p);
+    t.five_m = five_times_two_to(prm.p);
     return t;
 }
 
@@ -241,7 +246,7 @@ __device__ __forceinline__ EstimatorTables stage_lc_only(LcLds<M1> &lds, const s
     t.n_tbl = prm.n_tbl;
     t.lc_min_zeros = prm.lc_min_zeros;
     t.alpha_mm = prm.alpha_mm;
-    t.five_m = 5.0f * (float)(1 << prm.p);
+    t.five_m = five_times_two_to(prm.p);
     return t;
 }
 
@@ -274,7 +279,7 @@ __device__ __forceinline__ EstimatorTables stage_tables_compact(CompactEstimator
     t.n_tbl = prm.n_tbl;
     t.lc_min_zeros = prm.lc_min_zeros;
     t.alpha_mm = prm.alpha_mm;
-    t.five_m = 5.0f * (float)(1 << prm.p);
+    t.five_m = five_times_two_to(prm.p);
     return t;
 }
 

@@ -185,9 +185,20 @@ __device__ unsigned long long csr_phase_ticks[16];
         }                                                                                            \
     } while (0)
 #define SS_TICK_START() unsigned long long tick_ = wall_clock64()
+// the finish launch's timeline: slot 8 = earliest start of a workgroup, slots 9.. = latest time any workgroup passed mark i
+#define SS_MARK_START()                                                          \
+    do {                                                                         \
+        if (threadIdx.x == 0) atomicMin(&csr_phase_ticks[8], wall_clock64());    \
+    } while (0)
+#define SS_MARK(i)                                                               \
+    do {                                                                         \
+        if (threadIdx.x == 0) atomicMax(&csr_phase_ticks[i], wall_clock64());    \
+    } while (0)
 #else
 #define SS_TICK(i)
 #define SS_TICK_START()
+#define SS_MARK_START()
+#define SS_MARK(i)
 #endif
 
 // ---- level 0: every 4096-edge tile of the caller's list is sorted by key in LDS and written back as ONE contiguous tile (no global
@@ -671,7 +682,9 @@ __device__ __forceinline__ void scan_bucket_nodes(const uint32_t *cnt, uint32_t 
                     const int slices = (int)((c + 1 + SS_MEGA_SLICE - 1) / SS_MEGA_SLICE);  // + 1: the implicit self loop
                     const int m = atomicAdd(&o.mega_count[0], 1);
                     const int first = atomicAdd(&o.mega_count[1], slices);
-                    reinterpret_cast<int4 *>(o.mega_rows)[m] = make_int4((int)(node0 + b0 + k), first, slices, 0);
+                    int4 *desc = reinterpret_cast<int4 *>(o.mega_rows + (int64_t)SS_MEGA_DESC_WORDS * m);
+                    desc[0] = make_int4((int)(node0 + b0 + k), first, slices, 0);  // {row, first slice, slices, ticket (MinHash side)}
+                    desc[1] = make_int4(0, 0, 0, 0);                               // {ticket (HLL side), -, -, -}
                 } else {
                     o.hub_rows[atomicAdd(o.hub_count, 1)] = (int32_t)(node0 + b0 + k);
                 }
@@ -751,18 +764,24 @@ struct RunEdges {
     __device__ __forceinline__ uint32_t prepare(int b0, int n, unsigned long long *o0_sum = nullptr) const
     {
         const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-        uint32_t len[kPer], addr[kPer], run = 0;
+        // (every descriptor word is loaded UNCONDITIONALLY from a clamped index and only its use is predicated: loads under
+        // `if (i < n)` are awaited branch by branch -- kPer dependent round trips at the head of every bucket, 2 of its 5 us)
+        uint32_t len[kPer], addr[kPer], o0[kPer], o1[kPer], ts[kPer], run = 0;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const int i = threadIdx.x * kPer + j;
-            len[j] = addr[j] = 0;
-            if (i < n) {
-                const int t = b0 + i;
-                const uint32_t o0 = row0[t];
-                len[j] = row1[t] - o0;
-                if (o0_sum) *o0_sum += o0;
-                addr[j] = (tstart ? tstart[t] : (uint32_t)t * (uint32_t)kTile) + o0;
-            }
+            const int t = i < n ? b0 + i : 0;  // (word 0 of a descriptor row always exists)
+            o0[j] = row0[t];
+            o1[j] = row1[t];
+            ts[j] = tstart ? tstart[t] : (uint32_t)t * (uint32_t)kTile;
+        }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = threadIdx.x * kPer + j;
+            const bool in = i < n;
+            len[j] = in ? o1[j] - o0[j] : 0u;
+            addr[j] = in ? ts[j] + o0[j] : 0u;
+            if (o0_sum && in) *o0_sum += o0[j];
             run += len[j];
         }
         uint32_t inc = run;
@@ -954,7 +973,9 @@ struct DenseRunArgs {
         uint32_t carry = 0;
         for (int t0 = t_lo; t0 < t_hi; t0 += (int)blockDim.x) {
             const int t = t0 + threadIdx.x;
-            const uint32_t len = t < t_hi ? row1[t] - row0[t] : 0u;
+            const int tc = t < t_hi ? t : 0;  // (unconditional loads from a clamped index, see RunEdges::prepare)
+            const uint32_t d0 = row0[tc], d1 = row1[tc];
+            const uint32_t len = t < t_hi ? d1 - d0 : 0u;
             uint32_t inc = len;
 #pragma unroll
             for (int off = 1; off < kWave; off <<= 1) {
@@ -1098,23 +1119,89 @@ __global__ __launch_bounds__(kDenseThreads) void dense_place_runs_kernel(DenseRu
 // helper workgroups of the finish launch (blockIdx >= the number of fine buckets; see dense_helper above for the protocol and why
 // the bound on their number excludes a deadlock): wait until every bucket workgroup has decided, leave if nothing was registered,
 // otherwise count, meet the other helpers at a counter barrier, place
+// the helpers' records between their two steps: the part of the finish step's image behind DenseRunLds (a share is at most
+// kDensePart edges + one run: 12 288 records)
+constexpr int kHelperStashWord = (int)((sizeof(DenseRunLds) + 255) / 256 * 256 / 4);
+constexpr int kHelperStashCap = kFinishCap - kHelperStashWord;
+
 template <bool PACKED>
-__device__ __forceinline__ void dense_run_helper(DenseRunLds &lds, int helper, int n_buckets, const DenseRunWork &w, const RowOutputs &o,
-                                                 const DenseRunArgs &dense)
+__device__ __forceinline__ void dense_run_helper(DenseRunLds &lds, uint32_t *stash, int helper, int n_buckets, const DenseRunWork &w,
+                                                 const RowOutputs &o, const DenseRunArgs &dense)
 {
     wait_for_count(&dense.count[kArriveBase], kArriveWords, 16, n_buckets);
+    SS_MARK(10);
     const int n_dense = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int n_shares = __hip_atomic_load(&dense.count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n_shares == 0) return;  // every unskewed graph
-    dense_count_run_shares<PACKED, kRunThreads>(lds, helper, dense.helpers, n_dense, n_shares, w);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&dense.count[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto counted = [&]() {  // every helper: this workgroup's counters are out -> wait for everybody's
+        __syncthreads();
+        SS_MARK(11);
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&dense.count[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        wait_for_count(&dense.count[3], 1, 0, dense.helpers);
+        SS_MARK(12);
+    };
+    if (!PACKED || n_shares > dense.helpers) {  // (uniform over the launch) some helper has several shares: two sweeps over each
+        dense_count_run_shares<PACKED, kRunThreads>(lds, helper, dense.helpers, n_dense, n_shares, w);
+        counted();
+        dense_place_run_shares<PACKED, kRunThreads>(lds, helper, dense.helpers, n_dense, n_shares, w, o);
+        SS_MARK(13);
+        return;
     }
-    wait_for_count(&dense.count[3], 1, 0, dense.helpers);
-    dense_place_run_shares<PACKED, kRunThreads>(lds, helper, dense.helpers, n_dense, n_shares, w, o);
+    // At most ONE share per helper (every graph but the most skewed): the share's records stay in LDS between the two steps, as in
+    // an ordinary bucket's workgroup -- no second descriptor table, no second gather (rank^-0.5 endpoints at collab size: the
+    // placing step 13.4 -> 7.5 us, the finish launch 42 -> 35)
+    const int nb = 1 << w.node_shift;
+    constexpr int kPerThread = 1024 / kRunThreads;  // node counters per thread
+    const bool mine = helper < n_shares;  // workgroup-uniform
+    DenseRunBucket b = {};
+    RunEdges<PACKED, kRunThreads> edges = {};
+    uint32_t total = 0, off[kPerThread];
+    bool stashed = false;
+    int d = 0;
+    if (mine) {
+        edges = locate_run_share<PACKED, kRunThreads>(lds, helper, n_dense, w, b);
+        d = lds.desc;
+        total = edges.resident() ? lds.runs.start[edges.t_hi - edges.t_lo] : 0u;
+        stashed = edges.resident() && total <= (uint32_t)kHelperStashCap;
+        for (int i = threadIdx.x; i < nb; i += kRunThreads) lds.cnt[i] = 0;
+        __syncthreads();
+        if (stashed) edges.for_each_stash(stash, [&](int, int y) { atomicAdd(&lds.cnt[y], 1u); });
+        else edges.for_each([&](int, int y) { atomicAdd(&lds.cnt[y], 1u); });
+        __syncthreads();
+        uint32_t *sum = w.node_cnt + (size_t)d * 1024;
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            const int i = threadIdx.x + k * kRunThreads;
+            const uint32_t c = i < nb ? lds.cnt[i] : 0u;
+            off[k] = c ? atomicAdd(&sum[i], c) : 0u;  // (where this share's edges of node i start inside the node's row)
+        }
+    }
+    counted();
+    if (mine) {
+        const uint32_t *sum = w.node_cnt + (size_t)d * 1024;
+        // (the totals were formed by other workgroups' agent-scope atomics in this launch: read them past the L1)
+        for (int i = threadIdx.x; i < nb; i += kRunThreads)
+            lds.cnt[i] = __hip_atomic_load(const_cast<uint32_t *>(sum) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        scan_bucket_nodes(lds.cnt, lds.excl, lds.wave_tot, nb, (int64_t)b.bucket << w.node_shift, w.N, b.base, b.n, helper == b.first_share, o);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            const int i = threadIdx.x + k * kRunThreads;
+            if (i < nb) lds.cnt[i] = lds.excl[i] + off[k];
+        }
+        __syncthreads();
+        const unsigned long long cbase = b.base;
+        int32_t *col = w.col;
+        auto place = [&](int x, int y) { col[cbase + atomicAdd(&lds.cnt[y], 1u)] = x; };
+        if (stashed) edges.replay(stash, total, place);
+        else edges.for_each(place);
+    }
+    SS_MARK(13);
 }
 
 template <bool PACKED>
@@ -1129,9 +1216,12 @@ __global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel pa
     __shared__ unsigned long long red_base[kRunThreads / kWave], red_max[kRunThreads / kWave];
     __shared__ uint32_t red_n[kRunThreads / kWave];
     SS_CSR_SKIP(o.skip);
+    SS_MARK_START();
     if ((int64_t)blockIdx.x >= fine_buckets) {  // helper workgroup
         const DenseRunWork w = {par, staged, node_shift, src_bits, N, dense.list, dense.share_lo, dense.node_cnt, dense.share_off, col};
-        dense_run_helper<PACKED>(*reinterpret_cast<DenseRunLds *>(lds.image), (int)(blockIdx.x - fine_buckets), (int)fine_buckets, w, o, dense);
+        static_assert(kHelperStashCap >= kDensePart + kTile, "a helper's share fits behind its tables");
+        dense_run_helper<PACKED>(*reinterpret_cast<DenseRunLds *>(lds.image), reinterpret_cast<uint32_t *>(lds.image) + kHelperStashWord,
+                                 (int)(blockIdx.x - fine_buckets), (int)fine_buckets, w, o, dense);
         return;
     }
     SS_TICK_START();
@@ -1152,7 +1242,10 @@ __global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel pa
             n += row1[t] - o0;
         }
     }
-    if (blockIdx.x == 0)  // the first workgroup also reduces max(edge_index) + 1 (the self-loop count, hashing.py:148)
+    // the LAST bucket's workgroup also reduces max(edge_index) + 1 (the self-loop count, hashing.py:148) -- not the first: under
+    // id-correlated skew bucket 0 is the dense one the helpers wait for
+    const bool reducer = (int64_t)blockIdx.x == fine_buckets - 1;
+    if (reducer)
         for (int t = threadIdx.x; t < tiles0; t += kRunThreads) {
             const unsigned long long v = tile_max[t];
             mx = v > mx ? v : mx;
@@ -1175,9 +1268,9 @@ __global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel pa
         n += red_n[w];
         mx = red_max[w] > mx ? red_max[w] : mx;
     }
-    if (threadIdx.x == 0) {
-        if (blockIdx.x == 0) *n_self = mx;
-        if ((int64_t)blockIdx.x == fine_buckets - 1) o.rowptr[N] = (int64_t)(base + n);  // the last bucket ends the edge list
+    if (threadIdx.x == 0 && reducer) {
+        *n_self = mx;
+        o.rowptr[N] = (int64_t)(base + n);  // the last bucket ends the edge list
     }
     dense.row0 = row0;
     dense.row1 = row1;
@@ -1187,9 +1280,11 @@ __global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel pa
     const int nb = 1 << node_shift;  // <= 1024 nodes
     if (n > (uint32_t)kDenseMin) {  // (workgroup-uniform) does not fit the image: split over several workgroups by the dense steps
         dense.register_bucket(lds, base, n, nb);
+        SS_MARK(14);
         return;
     }
     dense.arrive();
+    SS_MARK(15);
     uint32_t *cnt = lds.cnt;
     for (int i = threadIdx.x; i < nb; i += kRunThreads) cnt[i] = 0;
     __syncthreads();
@@ -1213,6 +1308,7 @@ __global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel pa
     SS_TICK(3);
     for (uint32_t q = threadIdx.x; q < n; q += kRunThreads) col[base + q] = lds.image[q];
     SS_TICK(4);
+    SS_MARK(9);
 }
 
 struct Workspace {
@@ -1406,6 +1502,10 @@ extern "C" int ss_csr_timing_read(unsigned long long *out16, int reset)
         if (hipMemcpyToSymbol(HIP_SYMBOL(ss::csr_phase_ticks), z, 16 * 8) != hipSuccess) return SS_ERR_LAUNCH;
     }
     return SS_OK;
+}
+extern "C" int ss_csr_timing_write(const unsigned long long *in16)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(ss::csr_phase_ticks), in16, 16 * 8) == hipSuccess ? SS_OK : SS_ERR_LAUNCH;
 }
 #endif
 

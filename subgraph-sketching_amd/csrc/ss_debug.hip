@@ -18,7 +18,10 @@ struct Span {
     int tag;
 };
 std::vector<Span> g_spans;
+std::atomic<int64_t> g_hub_calls{0};
 }  // namespace
+
+void note_hub_call() { g_hub_calls.fetch_add(1, std::memory_order_relaxed); }
 
 ProfileSpan::ProfileSpan(hipStream_t s, int tag_) : stream(s), tag(tag_)
 {
@@ -41,6 +44,11 @@ ProfileSpan::~ProfileSpan()
 }
 
 }  // namespace ss
+
+extern "C" int64_t ss_debug_hub_calls(int32_t reset)
+{
+    return reset ? ss::g_hub_calls.exchange(0, std::memory_order_relaxed) : ss::g_hub_calls.load(std::memory_order_relaxed);
+}
 
 extern "C" int ss_profile_enable(uint32_t tag_mask)
 {

@@ -14,12 +14,13 @@
 // lane hashes ITS neighbour (64 hashes in parallel) and scatter-maxes that neighbour's single HLL register
 // into the wave's LDS row; then the wave walks the batch with v_readlane: the neighbour's hash is
 // wave-uniform (SGPR pair), each lane evaluates its own permutations on it.
-// Hub rows (see ss_propagate.hip) get a 16-wave workgroup: waves take alternate 64-neighbour batches and
-// combine through LDS atomics.
+// Hub rows are hub units (ss_hub.hpp): a whole workgroup per row or slice of a row, waves take alternate 64-neighbour
+// batches and combine through LDS atomics -- the HLL side hosted by the leading workgroups of hll_first_hop_kernel's launch,
+// the MinHash side by the fused kernel's (ss_fused_hop.hip) or by first_hop_hub_kernel, a launch of its own.
 #include <cstdlib>
 #include <type_traits>
 
-#include "ss_walks.hpp"
+#include "ss_hub.hpp"
 
 namespace ss {
 
@@ -139,9 +140,13 @@ __global__ __launch_bounds__(256) void first_hop_rows_kernel(GraphArgs g, const 
 // chain); the one-row-per-wave kernel above is a single dependent chain per wave and takes 4x longer for this.
 constexpr int kHllRows = 4;  // (2, 6 and 8 measured the same 25 us on the bench graph: the kernel is not bound by its prefetch depth)
 
-__global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, uint8_t *__restrict__ hll_out,
-                                                            float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm,
-                                                            bool skip_hubs)
+// PPL only matters to the leading workgroups (hub units, ss_hub.hpp): with hub_mh_out they also serve the hop-1 MinHash table
+// (P = 64 * PPL) -- ss_fused_hop_stage's row kernel has no register to spare for them.  The register allocator is held to the 64
+// VGPRs of the row path's eight wavefronts per SIMD; what the MinHash units spill they spill on their own, cold, path.
+template <int PPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void hll_first_hop_kernel(
+    GraphArgs g, int p, uint8_t *__restrict__ hll_out, float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm, bool skip_hubs,
+    int hub_blocks, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb, uint32_t *__restrict__ hub_mh_out)
 {
     // only the linear-counting table is staged (this kernel is only launched for p = 8: 257 entries): a hop-1 row leaves the
     // linear-counting range at 147 neighbours, and those few read raw / bias from global memory.  17 KB of LDS and 60 VGPRs
@@ -152,12 +157,27 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
     report_hub_rows(g);
     EstimatorTables est;
     if (want_cards) est = stage_lc_only(lds, prm);
+    if ((int)blockIdx.x < hub_blocks) {  // workgroup-uniform: a leading workgroup serves hub units of the hop-1 HLL table (its rows
+                                         // leave the linear-counting range: raw / bias come from global memory)
+        static_assert(sizeof(FirstHopHubLds<PPL>) <= sizeof(rows), "the hub units' LDS rows live in the row image");
+        FirstHopHubLds<PPL> &hub = *reinterpret_cast<FirstHopHubLds<PPL> *>(&rows[0][0]);
+        // (with hub_mh_out the first QUARTER of the leading workgroups serves the HLL units, the rest the MinHash units -- tickets of
+        // their own; a MinHash unit costs several times an HLL unit, and this launch is a short one to hide them in)
+        const int first = hub_mh_out ? hub_blocks / 4 : hub_blocks;
+        if ((int)blockIdx.x < first)
+            first_hop_hub_units<PPL, kHubLeadWaves, false, true>(g, (int)blockIdx.x, first, nullptr, nullptr, nullptr, p, hll_out, cards_out,
+                                                                 cards_stride, est, want_cards, hub, false);
+        else
+            first_hop_hub_units<PPL, kHubLeadWaves, true, false>(g, (int)blockIdx.x - first, hub_blocks - first, pa, pb, hub_mh_out, p, nullptr,
+                                                                 nullptr, 0, est, false, hub, kForceExactFirstHop);
+        return;
+    }
     const int l = threadIdx.x & (kRow - 1);
     const int grp = threadIdx.x / kRow;
     // kHllRows rows per lane group, one after the other through the same LDS row image; the row bounds and the first
     // neighbour ids of ALL of them are requested up front, so the two dependent global round trips (rowptr -> col) of
     // the later rows hide under the work of the earlier ones
-    const int64_t first = g.row0 + ((int64_t)blockIdx.x * (blockDim.x / kRow) + grp) * kHllRows;
+    const int64_t first = g.row0 + ((int64_t)((int)blockIdx.x - hub_blocks) * (blockDim.x / kRow) + grp) * kHllRows;
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
     uint32_t *row = rows[grp];
     int64_t rbs[kHllRows];
@@ -237,9 +257,10 @@ __global__ __launch_bounds__(256) void hll_first_hop_kernel(GraphArgs g, int p, 
     }
 }
 
+// ---- hub units as a launch of their own (16 wavefronts per workgroup) --------------------------------------------------------
 constexpr int kHubThreads = 1024;
 constexpr int kHubWaves = kHubThreads / kWave;
-constexpr int kHubGrid = 256;  // one workgroup per CU; workgroups beyond the hub count exit at once
+constexpr int kHubGrid = 256;  // one workgroup per CU; workgroups beyond the unit count exit at once
 
 template <int PPL, bool DO_MH, bool DO_HLL>
 __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g, const uint64_t *__restrict__ pa,
@@ -248,178 +269,14 @@ __global__ __launch_bounds__(kHubThreads) void first_hop_hub_kernel(GraphArgs g,
                                                                     int64_t cards_stride, ss_hll_params prm)
 {
     __shared__ EstimatorLds lds;
-    __shared__ __attribute__((aligned(16))) uint32_t hll_row[256];
-    __shared__ uint32_t mh_row[PPL * kWave];
-    __shared__ int s_last, s_m;
-    const int n_hubs = *g.hub_count;
-    const int n_mega = g.mega_count ? g.mega_count[0] : 0;
-    const int n_slices = g.mega_count ? g.mega_count[1] : 0;
-    if ((int)blockIdx.x >= n_hubs && n_mega == 0) return;  // the common case (no hub rows) costs two scalar loads per workgroup
+    __shared__ FirstHopHubLds<PPL> hub;
+    const HubCounts n = hub_counts(g);
+    if ((int)blockIdx.x >= n.hubs + n.slices) return;  // the common case (no hub rows) costs three scalar loads per workgroup
     const bool want_cards = DO_HLL && cards_out != nullptr;
-    EstimatorTables est;
+    EstimatorTables est = {};
     if (want_cards) est = stage_tables(lds, prm);
-    constexpr int P = PPL * kWave;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    uint64_t a[PPL], b[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-        a[q] = DO_MH ? pa[lane + kWave * q] : 0ULL;
-        b[q] = DO_MH ? pb[lane + kWave * q] : 0ULL;
-    }
-    const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
-
-    // all 16 waves hash the neighbours t in [lo, hi) of row i (batches of 64, one batch per wave and step); the combined
-    // partial rows are left in mh_row / hll_row (LDS)
-    auto walk = [&](int64_t i, const int32_t *nb, int deg, int lo, int hi) {
-        if (threadIdx.x < 256) hll_row[threadIdx.x] = 0u;
-        if (threadIdx.x < P) mh_row[threadIdx.x] = 0xFFFFFFFFu;
-        __syncthreads();
-        uint32_t acc[PPL];
-#pragma unroll
-        for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
-        // slice = the same walk over nb + lo with the degree counted from lo (slot deg - lo is the implicit self loop)
-        if (DO_HLL) first_hop_walk<PPL, false, true>(nb + lo, deg - lo, hi - lo, i, wave, kHubWaves, p, a, b, acc, hll_row, lane);
-        // MinHash: the two-phase walk (ss_walks.hpp: 4-5 instead of 10 VALU per neighbour and permutation) over this wavefront's
-        // batches; a wavefront whose share is ambiguous (duplicated minimum, key collision) redoes its share exactly
-        if (DO_MH && wave * kWave < hi - lo) {  // (wave-uniform) the wavefront has at least one batch
-            const bool amb = kForceExactFirstHop ||
-                             first_hop_minhash_fast<PPL>(nb + lo, deg - lo, hi - lo, i, a, b, acc, lane, wave, kHubWaves);
-            if (__any(amb)) {
-#pragma unroll
-                for (int q = 0; q < PPL; ++q) acc[q] = 0xFFFFFFFFu;
-                first_hop_walk<PPL, true, false>(nb + lo, deg - lo, hi - lo, i, wave, kHubWaves, p, a, b, acc, hll_row, lane);
-            }
-        }
-        if (DO_MH) {
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) atomicMin(&mh_row[lane + kWave * q], acc[q]);
-        }
-        __syncthreads();
-    };
-    // wave 0 stores the finished row (+ its cardinality): lane l holds MinHash values l, l + 64, .. and HLL registers 4l .. 4l+3
-    auto finish = [&](int64_t i, const uint32_t (&mh)[PPL], uint32_t regs) {
-        if (DO_MH) {
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) {
-                mh_out[i * P + lane + kWave * q] = mh[q];
-                mirror_mh1(g.mir, i * P + lane + kWave * q, mh[q]);
-            }
-        }
-        if (DO_HLL) {
-            *reinterpret_cast<uint32_t *>(hll_out + i * 256 + 4 * lane) = regs;
-            mirror_hll4(g.mir, i * 256 + 4 * lane, regs);
-        }
-        if (want_cards) {
-            int nonzero = 0;
-            float hsum = 0.0f;
-            hll_dword_stats(regs, nonzero, hsum);
-            for (int off = 1; off < kWave; off <<= 1) {
-                nonzero += __shfl_xor(nonzero, off);
-                hsum += __shfl_xor(hsum, off);
-            }
-            if (lane == 0) {
-                const float card = hll_estimate(est, 256 - nonzero, hsum);
-                cards_out[i * cards_stride] = card;
-                mirror_card(g.mir, i * cards_stride, card);
-            }
-        }
-    };
-
-    for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
-        const int64_t i = g.hub_rows[h];
-        if (!g.owns(i)) continue;  // workgroup-uniform
-        const int64_t rb = g.rowptr[i];
-        const int deg = (int)(g.rowptr[i + 1] - rb);
-        const int total = deg + (i < n_self ? 1 : 0);
-        walk(i, g.col + rb, deg, 0, total);
-        if (wave == 0) {
-            uint32_t mh[PPL];
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) mh[q] = DO_MH ? mh_row[lane + kWave * q] : 0u;
-            finish(i, mh, DO_HLL ? pack_hll_quad(hll_row, lane) : 0u);
-        }
-        __syncthreads();
-    }
-
-    // ---- mega rows: slices of SS_MEGA_SLICE neighbours spread over all workgroups, combined by the last one to finish
-    // (see propagate_hub_kernel); scratch layout per slice: MinHash u32[P] (P <= 256: within the first 1024 B ... P = 128
-    // uses 512 B) then the packed HLL row at byte 512
-    // one list of the slices of ALL mega rows, continuing the round robin of the hub rows (see propagate_hub_kernel)
-    for (int gs = (int)((blockIdx.x + gridDim.x - (unsigned)n_hubs % gridDim.x) % gridDim.x); gs < n_slices; gs += gridDim.x) {
-        for (int t = threadIdx.x; t < n_mega; t += kHubThreads) {
-            const int4 d = reinterpret_cast<const int4 *>(g.mega_rows)[t];
-            if (gs >= d.y && gs < d.y + d.z) s_m = t;
-        }
-        __syncthreads();
-        const int m = s_m;
-        const int4 e = reinterpret_cast<const int4 *>(g.mega_rows)[m];
-        const int64_t i = e.x;
-        if (!g.owns(i)) { __syncthreads(); continue; }  // workgroup-uniform
-        const int64_t rb = g.rowptr[i];
-        const int deg = (int)(g.rowptr[i + 1] - rb);
-        const int total = deg + (i < n_self ? 1 : 0);
-        {
-            const int sl = gs - e.y;
-            const int lo = sl * SS_MEGA_SLICE < total ? sl * SS_MEGA_SLICE : total;
-            const int hi = lo + SS_MEGA_SLICE < total ? lo + SS_MEGA_SLICE : total;
-            walk(i, g.col + rb, deg, lo, hi);
-            uint8_t *mine = g.mega_scratch + (int64_t)(e.y + sl) * kMegaSlot;
-            if (wave == 0) {
-                if (DO_MH) {
-#pragma unroll
-                    for (int q = 0; q < PPL; ++q) coherent_store(reinterpret_cast<uint32_t *>(mine) + lane + kWave * q, mh_row[lane + kWave * q]);
-                }
-                if (DO_HLL) coherent_store(reinterpret_cast<uint32_t *>(mine + kMegaHllOffset) + lane, pack_hll_quad(hll_row, lane));
-            }
-            publish_drain();  // every wave: the slot stores are acknowledged before the barrier that precedes the ticket
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int prev = take_ticket(&g.mega_rows[4 * m + 3]);
-                s_last = prev == e.z - 1;
-                if (s_last) reset_ticket(&g.mega_rows[4 * m + 3]);
-            }
-            __syncthreads();
-            if (s_last) {  // workgroup-uniform.  All 16 waves read the slots (wave w: slots w, w + 16, ...), combined through the
-                           // LDS rows of the walk (which the barrier above has released), wave 0 stores
-                uint32_t mh[PPL], regs = 0u;
-#pragma unroll
-                for (int q = 0; q < PPL; ++q) mh[q] = 0xFFFFFFFFu;
-                for (int s2 = wave; s2 < e.z; s2 += kHubWaves) {
-                    const uint8_t *part = g.mega_scratch + (int64_t)(e.y + s2) * kMegaSlot;
-                    if (DO_MH) {
-#pragma unroll
-                        for (int q = 0; q < PPL; ++q) {
-                            const uint32_t v = coherent_load(reinterpret_cast<const uint32_t *>(part) + lane + kWave * q);
-                            mh[q] = v < mh[q] ? v : mh[q];
-                        }
-                    }
-                    if (DO_HLL) {
-                        const uint32_t v = coherent_load(reinterpret_cast<const uint32_t *>(part + kMegaHllOffset) + lane);
-                        regs = pk_max_u16(regs & 0x00FF00FFu, v & 0x00FF00FFu) | pk_max_u16(regs & 0xFF00FF00u, v & 0xFF00FF00u);
-                    }
-                }
-                if (threadIdx.x < 256) hll_row[threadIdx.x] = 0u;
-                if (threadIdx.x < P) mh_row[threadIdx.x] = 0xFFFFFFFFu;
-                __syncthreads();
-                if (DO_MH) {
-#pragma unroll
-                    for (int q = 0; q < PPL; ++q) atomicMin(&mh_row[lane + kWave * q], mh[q]);
-                }
-                if (DO_HLL) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) atomicMax(&hll_row[4 * lane + k], (regs >> (8 * k)) & 0xFFu);
-                }
-                __syncthreads();
-                if (wave == 0) {
-#pragma unroll
-                    for (int q = 0; q < PPL; ++q) mh[q] = DO_MH ? mh_row[lane + kWave * q] : 0u;
-                    finish(i, mh, DO_HLL ? pack_hll_quad(hll_row, lane) : 0u);
-                }
-            }
-            __syncthreads();
-        }
-    }
+    first_hop_hub_units<PPL, kHubWaves, DO_MH, DO_HLL>(g, (int)blockIdx.x, (int)gridDim.x, pa, pb, mh_out, p, hll_out, cards_out, cards_stride, est,
+                                                       want_cards, hub, kForceExactFirstHop);
 }
 
 int launch_first_hop_hub_only(const GraphArgs &g, const uint64_t *a, const uint64_t *b, int P, uint32_t *mh_out, int p, uint8_t *hll_out,
@@ -444,6 +301,7 @@ int launch_first_hop_v(const GraphArgs &g, const uint64_t *a, const uint64_t *b,
     }
     SS_LAUNCH_CHECK();
     if (hubs) {
+        note_hub_call();
         hipLaunchKernelGGL((first_hop_hub_kernel<PPL, DO_MH, DO_HLL>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p,
                            hll_out, cards_out, cards_stride, prm);
         SS_LAUNCH_CHECK();
@@ -479,14 +337,30 @@ void launch_minhash_rows(const GraphArgs &g, const uint64_t *a, const uint64_t *
 }
 
 // HLL first hop of the regular rows alone (ss_fused_hop_stage owns the hub pass that follows)
-int launch_hll_first_hop_rows(const GraphArgs &g, int p, uint8_t *hll_out, float *cards_out, int64_t cards_stride, const ss_hll_params &prm,
-                              bool skip_hubs, hipStream_t s)
+// (`lead` leading workgroups serve the hub units of the HLL table and -- with hub_mh_out, P = 64 * PPL values per row from the
+// permutations a / b -- of the hop-1 MinHash table, ss_hub.hpp; 0: the caller launches first_hop_hub_kernel)
+template <int PPL>
+static int launch_hll_rows(const GraphArgs &g, int p, uint8_t *hll_out, float *cards_out, int64_t cards_stride, const ss_hll_params &prm,
+                           bool skip_hubs, int lead, const uint64_t *a, const uint64_t *b, uint32_t *hub_mh_out, hipStream_t s)
 {
     ProfileSpan span(s, SS_PROF_FIRST_HOP_HLL);
-    hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows))), dim3(256), 0, s, g, p, hll_out,
-                       cards_out, cards_stride, prm, skip_hubs);
+    hipLaunchKernelGGL((hll_first_hop_kernel<PPL>), dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows) + lead)), dim3(256), 0, s, g,
+                       p, hll_out, cards_out, cards_stride, prm, skip_hubs, lead, a, b, hub_mh_out);
     SS_LAUNCH_CHECK();
     return SS_OK;
+}
+
+int launch_hll_first_hop_rows(const GraphArgs &g, int p, uint8_t *hll_out, float *cards_out, int64_t cards_stride, const ss_hll_params &prm,
+                              bool skip_hubs, int lead, const uint64_t *a, const uint64_t *b, uint32_t *hub_mh_out, int P, hipStream_t s)
+{
+    if (lead == 0 || !hub_mh_out) return launch_hll_rows<1>(g, p, hll_out, cards_out, cards_stride, prm, skip_hubs, lead, nullptr, nullptr, nullptr, s);
+    lead *= 2;  // (a quarter for the HLL units, the rest for the MinHash units)
+    switch (P / kWave) {
+        case 1: return launch_hll_rows<1>(g, p, hll_out, cards_out, cards_stride, prm, skip_hubs, lead, a, b, hub_mh_out, s);
+        case 2: return launch_hll_rows<2>(g, p, hll_out, cards_out, cards_stride, prm, skip_hubs, lead, a, b, hub_mh_out, s);
+        case 3: return launch_hll_rows<3>(g, p, hll_out, cards_out, cards_stride, prm, skip_hubs, lead, a, b, hub_mh_out, s);
+        default: return launch_hll_rows<4>(g, p, hll_out, cards_out, cards_stride, prm, skip_hubs, lead, a, b, hub_mh_out, s);
+    }
 }
 
 template <int PPL>
@@ -497,29 +371,24 @@ int launch_first_hop(const GraphArgs &g, const uint64_t *a, const uint64_t *b, u
         // both sketches: the latency-optimised HLL kernel + the MinHash kernel beat the combined kernel (37 + 134 us vs
         // 184 us on the bench graph); one hub pass serves both
         const bool hubs = g.hub_rows && g.hub_count;
-        {
-            ProfileSpan span(s, SS_PROF_FIRST_HOP_HLL);
-            hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows))), dim3(256), 0, s, g, p,
-                               hll_out, cards_out, cards_stride, prm, hubs);
-        }
-        SS_LAUNCH_CHECK();
+        const int lead = hub_lead_blocks(hubs);
+        const int rc = launch_hll_first_hop_rows(g, p, hll_out, cards_out, cards_stride, prm, hubs, lead, a, b, mh_out, PPL * kWave, s);
+        if (rc != SS_OK) return rc;
         {
             ProfileSpan span(s, SS_PROF_FIRST_HOP_MH);
             launch_minhash_rows<PPL>(g, a, b, mh_out, p, prm, hubs, s);
         }
         SS_LAUNCH_CHECK();
+        if (lead > 0) return SS_OK;  // (the hub units of both tables were hosted by the HLL launch)
         return launch_first_hop_hub_only(g, a, b, PPL * kWave, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
     }
     if (mh_out) return launch_first_hop_v<PPL, true, false>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, s);
     // HLL alone: 16-lane-per-row kernel for the regular rows, the cooperative hub kernel for the rest
     const bool hubs = g.hub_rows && g.hub_count;
-    {
-        ProfileSpan span(s, SS_PROF_FIRST_HOP_HLL);
-        hipLaunchKernelGGL(hll_first_hop_kernel, dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows))), dim3(256), 0, s, g, p,
-                           hll_out, cards_out, cards_stride, prm, hubs);
-    }
-    SS_LAUNCH_CHECK();
-    if (hubs) {
+    const int lead = hub_lead_blocks(hubs);
+    const int rc = launch_hll_first_hop_rows(g, p, hll_out, cards_out, cards_stride, prm, hubs, lead, nullptr, nullptr, nullptr, 0, s);
+    if (rc != SS_OK) return rc;
+    if (hubs && lead == 0) {
         hipLaunchKernelGGL((first_hop_hub_kernel<PPL, false, true>), dim3(kHubGrid), dim3(kHubThreads), 0, s, g, a, b, mh_out, p,
                            hll_out, cards_out, cards_stride, prm);
         SS_LAUNCH_CHECK();
@@ -547,7 +416,7 @@ static int hub_only(const GraphArgs &g, const uint64_t *a, const uint64_t *b, ui
 int launch_first_hop_hub_only(const GraphArgs &g, const uint64_t *a, const uint64_t *b, int P, uint32_t *mh_out, int p, uint8_t *hll_out,
                               float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
 {
-    if (!g.hub_rows || !g.hub_count) return SS_OK;
+    if (!g.hub_rows || !g.hub_count || (!mh_out && !hll_out)) return SS_OK;
     ProfileSpan span(stream, SS_PROF_HUB);
     switch (P / kWave) {
         case 1: return hub_only<1>(g, a, b, mh_out, p, hll_out, cards_out, cards_stride, prm, stream);

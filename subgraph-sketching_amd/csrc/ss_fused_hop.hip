@@ -22,11 +22,13 @@
 // its ids with vmcnt(0) -- vmcnt retires in order -- and so for every HLL row posted before it).  HLL side: one 16-lane DPP row
 // per destination (lane c = 16-byte chunk c of the 256-byte row); the first kHllInFlight = 7 neighbour chunks per lane are
 // requested into registers up front and the next kHllLds = 7 into LDS (global_load_lds_dwordx4; ids by one coalesced load per
-// lane group, handed out by DPP row_newbcast), the rest of rows longer than 14 after the MinHash walk (hll_row16_finish).  Hub rows are skipped by both sides and
-// served by the two hub kernels afterwards.  P = 64 * PPL, M = 256 (p = 8) only -- the shapes ss_first_hop has a kernel for.
+// lane group, handed out by DPP row_newbcast), the rest of rows longer than 14 after the MinHash walk (hll_row16_finish).  Hub rows are skipped by both sides:
+// they are hub units (ss_hub.hpp) hosted by the launches before and after this one -- not by this one: the kernel sits exactly at its
+// 96-VGPR budget, and a hub branch, whatever it contained, cost the row path 64 bytes of scratch and 30 us (round 4).
+// P = 64 * PPL, M = 256 (p = 8) only -- the shapes ss_first_hop has a kernel for.
 #include <cstdlib>
 
-#include "ss_walks.hpp"
+#include "ss_hub.hpp"
 
 namespace ss {
 
@@ -240,14 +242,17 @@ extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, 
     if (g.rows() == 0) return SS_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool hubs = g.hub_rows && g.hub_count;
+    // hub units: `lead` leading workgroups of the HLL first-hop launch serve both hop-1 tables, of the MinHash table hop both hop-2
+    // tables (0: launches of their own, as in rounds 1-3)
+    const int lead = hub_lead_blocks(hubs);
     const bool own_hop1 = cards1_out != nullptr;  // the hop-1 HLL table is computed here as well (build_hash_tables)
     if (own_hop1) {
         if (!cards2_out) return SS_ERR_INVALID_ARG;
-        int rc1 = launch_hll_first_hop_rows(g, p, hll1, cards1_out, cards_stride, p0, hubs, s);
+        int rc1 = launch_hll_first_hop_rows(g, p, hll1, cards1_out, cards_stride, p0, hubs, lead, a, b, lead > 0 ? mh1_out : nullptr, P, s);
         if (rc1 != SS_OK) return rc1;
         // ONE hub pass from node ids for both hop-1 sketches: the MinHash hub rows are not needed before the table hop below,
         // but computing them here saves the hub launch after the fused kernel
-        rc1 = launch_first_hop_hub_only(g, a, b, P, mh1_out, p, hll1, cards1_out, cards_stride, p0, s);
+        if (lead == 0) rc1 = launch_first_hop_hub_only(g, a, b, P, mh1_out, p, hll1, cards1_out, cards_stride, p0, s);
         if (rc1 != SS_OK) return rc1;
     }
     constexpr int rows_per_block = 4 * kFusedRows;
@@ -275,8 +280,9 @@ extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, 
     if (rc != SS_OK) return rc;
     if (!mh2_out)  // hop-2 HLL hub rows alone
         return launch_propagate_hub_only(g, nullptr, nullptr, hll1_in, hll2_out, cards2_out, cards_stride, p0, s);
-    // MinHash table hop of hop 2, then ONE hub pass for both hop-2 sketches
-    rc = launch_minhash_hop(g, mh1_out, mh2_out, hubs, s);
+    // MinHash table hop of hop 2; its launch hosts the hub units of both hop-2 tables (or ONE hub pass for both follows)
+    if (lead > 0) return launch_minhash_hop(g, mh1_out, mh2_out, hubs, lead, hll1_in, hll2_out, cards2_out, cards_stride, p0, s);
+    rc = launch_minhash_hop(g, mh1_out, mh2_out, hubs, 0, nullptr, nullptr, nullptr, 0, p0, s);
     if (rc != SS_OK) return rc;
     return launch_propagate_hub_only(g, mh1_out, mh2_out, hll1_in, hll2_out, cards2_out, cards_stride, p0, s);
 }

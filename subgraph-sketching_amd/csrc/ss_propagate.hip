@@ -11,30 +11,50 @@
 // cross-lane shuffles.  The implicit self loop (i < n_self) is one extra virtual neighbour.
 //
 // Hub rows (in-degree > graph.hub_threshold, listed by ss_csr_build) would serialise tens of thousands of
-// dependent 1 KiB loads on one wavefront (power-law graphs: ogbl-ppa, ogbl-citation2).  The row kernel
-// skips them and propagate_hub_kernel gives each of them a whole 16-wave workgroup: 32 MinHash / 64 HLL
-// neighbours per step, partials combined through LDS.
-#include "ss_walks.hpp"
+// dependent 1 KiB loads on one wavefront (power-law graphs: ogbl-ppa, ogbl-citation2).  The row wavefronts
+// skip them; the LEADING `hub_blocks` workgroups of the same launch walk them as hub units (ss_hub.hpp: a whole
+// workgroup per row or slice of a row, partials combined through LDS).
+#include "ss_hub.hpp"
 
 namespace ss {
 
 // TP / TM > 0: compile-time row sizes (fast path); 0: run-time.
 template <int TP, int TM>
-__global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint32_t *__restrict__ mh_in, uint32_t *__restrict__ mh_out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void propagate_kernel(GraphArgs g, const uint32_t *__restrict__ mh_in, uint32_t *__restrict__ mh_out,
                                                         int P_rt, const uint8_t *__restrict__ hll_in, uint8_t *__restrict__ hll_out,
                                                         int M_rt, float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm,
-                                                        bool skip_hubs)
+                                                        bool skip_hubs, int hub_blocks, const uint8_t *__restrict__ hub_hll_in,
+                                                        uint8_t *__restrict__ hub_hll_out, float *__restrict__ hub_cards_out)
 {
     __shared__ EstimatorLds lds;
-    const bool want_cards = cards_out != nullptr && hll_out != nullptr;
+    // (workgroup-uniform; the row workgroups of a MinHash-only launch must not pay for the tables a leading workgroup needs: staged
+    // by all 59 000 workgroups of the bench graph's launch they cost it 13 us)
+    const bool hub_hll_block = TP == 128 && TM == 256 && hub_hll_out != nullptr && (int)blockIdx.x < hub_blocks && (int)blockIdx.x >= hub_blocks / 2;
+    const bool want_cards = (cards_out != nullptr && hll_out != nullptr) || (hub_hll_block && hub_cards_out != nullptr);
     EstimatorTables est;
     if (want_cards) est = stage_tables(lds, prm);
+    if constexpr (TP == 128 && TM == 256) {  // (this instantiation is only ever launched for the MinHash rows alone)
+        if ((int)blockIdx.x < hub_blocks) {
+            // workgroup-uniform: a leading workgroup serves hub units (ss_hub.hpp) of this hop's MinHash table or -- with hub_hll_out,
+            // the second half of the leading workgroups, tickets of their own -- of its HLL table (ss_fused_hop_stage: the kernel
+            // that computes the HLL rows has no register to spare for them)
+            __shared__ TableHubLds<kHubLeadWaves> hub;
+            const int half = hub_hll_out ? hub_blocks / 2 : hub_blocks;
+            if ((int)blockIdx.x < half)
+                table_hub_units<kHubLeadWaves, true, false>(g, (int)blockIdx.x, half, mh_in, mh_out, nullptr, nullptr, nullptr, 0, est, false, hub);
+            else
+                table_hub_units<kHubLeadWaves, false, true>(g, (int)blockIdx.x - half, hub_blocks - half, nullptr, nullptr, hub_hll_in, hub_hll_out,
+                                                            hub_cards_out, cards_stride, est, hub_cards_out != nullptr, hub);
+            return;
+        }
+    }
 
+    const bool row_cards = cards_out != nullptr && hll_out != nullptr;
     const int P = TP ? TP : P_rt;
     const int M = TM ? TM : M_rt;
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform row id (readfirstlane makes the uniformity visible to the compiler: scalar loads, scalar loop control)
-    int64_t i = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    int64_t i = g.row0 + (int64_t)((int)blockIdx.x - hub_blocks) * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     if (g.row_list) {  // ss_minhash_hop_rows: the q-th wavefront computes row row_list[q]
         const int64_t q = i - g.row0;
         if (q >= g.n_list) return;
@@ -47,7 +67,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
 
     const int64_t rb = g.rowptr[i];
     const int deg = (int)(g.rowptr[i + 1] - rb);
-    if (skip_hubs && deg > g.hub_threshold) return;  // left to propagate_hub_kernel
+    if (skip_hubs && deg > g.hub_threshold) return;  // a hub unit (ss_hub.hpp)
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
     const int total = deg + (i < n_self ? 1 : 0);
     const int32_t *nb = g.col + rb;
@@ -90,7 +110,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
             if (act && sg == 0) {
                 *reinterpret_cast<u32x4 *>(hll_out + i * M + 16 * c) = acc;
                 mirror_hll16(g.mir, i * M + 16 * c, acc);
-                if (want_cards) {
+                if (row_cards) {
                     hll_dword_stats(acc.x, nonzero, hsum);
                     hll_dword_stats(acc.y, nonzero, hsum);
                     hll_dword_stats(acc.z, nonzero, hsum);
@@ -98,7 +118,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
                 }
             }
         }
-        if (want_cards) {
+        if (row_cards) {
             // lanes of sub-group 0 hold partial stats; the rest hold 0
             if (SG == kRow) {  // the 16 lanes of sub-group 0 are one DPP row
                 nonzero = row16_sum_i(nonzero);
@@ -119,19 +139,25 @@ __global__ __launch_bounds__(256) void propagate_kernel(GraphArgs g, const uint3
 }
 
 // HLL-only hop, 4 destinations per wavefront (fast path of ss_propagate when the MinHash sketch is absent)
-__global__ __launch_bounds__(256) void hll_propagate_row16_kernel(GraphArgs g, const uint8_t *__restrict__ hll_in,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void hll_propagate_row16_kernel(GraphArgs g, const uint8_t *__restrict__ hll_in,
                                                                   uint8_t *__restrict__ hll_out, float *__restrict__ cards_out,
-                                                                  int64_t cards_stride, ss_hll_params prm, bool skip_hubs)
+                                                                  int64_t cards_stride, ss_hll_params prm, bool skip_hubs, int hub_blocks)
 {
     __shared__ EstimatorLds lds;
     const bool want_cards = cards_out != nullptr;
     EstimatorTables est;
     if (want_cards) est = stage_tables(lds, prm);
+    if ((int)blockIdx.x < hub_blocks) {  // workgroup-uniform: a leading workgroup serves hub units of this hop's HLL table
+        __shared__ TableHubLds<kHubLeadWaves> hub;
+        table_hub_units<kHubLeadWaves, false, true>(g, (int)blockIdx.x, hub_blocks, nullptr, nullptr, hll_in, hll_out, cards_out, cards_stride, est,
+                                                    want_cards, hub);
+        return;
+    }
     // the 16 rows of this workgroup are dealt to its 16 lane groups in DEGREE order: the four rows that share a wavefront
     // then have similar degrees, and the walk of a wavefront lasts as long as its longest row
     __shared__ int s_deg[256 / kRow], s_owner[256 / kRow];
     const int grp = threadIdx.x / kRow, c16 = threadIdx.x & (kRow - 1);
-    const int64_t first = g.row0 + (int64_t)blockIdx.x * (blockDim.x / kRow);
+    const int64_t first = g.row0 + (int64_t)((int)blockIdx.x - hub_blocks) * (blockDim.x / kRow);
     {
         const int64_t r = first + grp;
         const int d = r < g.row1 ? (int)(g.rowptr[r + 1] - g.rowptr[r]) : -1;
@@ -148,177 +174,27 @@ __global__ __launch_bounds__(256) void hll_propagate_row16_kernel(GraphArgs g, c
     hll_hop_row16(g, row < g.row1 ? row : -1, skip_hubs, hll_in, hll_out, cards_out, cards_stride, est, want_cards, threadIdx.x & (kRow - 1));
 }
 
-// ---- hub rows: one 1024-thread workgroup (16 wavefronts) per row; P = 128, M = 256 only -------------------------
+// ---- hub units as a launch of their own (16 wavefronts per workgroup): the shapes / calls whose row kernel does not host them,
+// and SS_HUB_LAUNCHES=1; P = 128, M = 256 only
 constexpr int kHubThreads = 1024;
 constexpr int kHubWaves = kHubThreads / kWave;
-constexpr int kHubGrid = 256;  // one workgroup per CU; workgroups beyond the hub count exit at once
+constexpr int kHubGrid = 256;  // one workgroup per CU; workgroups beyond the unit count exit at once
 
+template <bool DO_MH, bool DO_HLL>
 __global__ __launch_bounds__(kHubThreads) void propagate_hub_kernel(GraphArgs g, const uint32_t *__restrict__ mh_in,
                                                                     uint32_t *__restrict__ mh_out, const uint8_t *__restrict__ hll_in,
                                                                     uint8_t *__restrict__ hll_out, float *__restrict__ cards_out,
                                                                     int64_t cards_stride, ss_hll_params prm)
 {
-    constexpr int P = 128, M = 256, CM = 32, CH = 16;
     __shared__ EstimatorLds lds;
-    __shared__ u32x4 part_mh[kHubWaves][CM];
-    __shared__ u32x4 part_hll[kHubWaves][CH];
-    __shared__ int s_last, s_m;
-    const int n_hubs = *g.hub_count;
-    const int n_mega = g.mega_count ? g.mega_count[0] : 0;
-    const int n_slices = g.mega_count ? g.mega_count[1] : 0;
-    if ((int)blockIdx.x >= n_hubs && n_mega == 0) return;  // the common case (no hub rows) costs two scalar loads per workgroup
-    const bool want_cards = cards_out != nullptr && hll_out != nullptr;
-    EstimatorTables est;
+    __shared__ TableHubLds<kHubWaves> hub;
+    const HubCounts n = hub_counts(g);
+    if ((int)blockIdx.x >= n.hubs + n.slices) return;  // the common case (no hub rows) costs three scalar loads per workgroup
+    const bool want_cards = DO_HLL && cards_out != nullptr;
+    EstimatorTables est = {};
     if (want_cards) est = stage_tables(lds, prm);
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
-
-    // all 16 waves walk the neighbours t in [lo, hi) of row i; wave 0 ends up with the combined partial rows
-    // (MinHash chunk `lane` in lanes 0..31, HLL chunk `lane - 32` in lanes 32..47)
-    // (wave w takes the CONTIGUOUS 64-neighbour chunks w, w + 16, ... of [lo, hi): ids by one coalesced load per chunk, handed
-    // out with v_readlane (MinHash) / DPP row broadcasts (HLL: 16 neighbours per lane group) -- one round trip per chunk instead
-    // of the generic walk's two per batch of four)
-    auto walk = [&](int64_t i, const int32_t *nb, int deg, int lo, int hi, u32x4 &mh_acc, u32x4 &hll_acc) {
-        if (mh_out) {
-            const int sg = lane >> 5, c = lane & 31;
-            u32x4 acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            for (int b = lo + wave * kWave; b < hi; b += kHubWaves * kWave)  // wave-uniform
-                acc = min4(acc, minhash_chunk64(mh_in, nb + b, deg - b, hi - b < kWave ? hi - b : kWave, i, lane));
-            acc = min4(acc, shfl_xor4(acc, 32));
-            if (sg == 0) part_mh[wave][c] = acc;
-        }
-        if (hll_out) {
-            const int sg = lane >> 4, c = lane & 15;
-            u32x4 acc = {0u, 0u, 0u, 0u};
-            for (int b = lo + wave * kWave; b < hi; b += kHubWaves * kWave) {
-                const int bg = b + kRow * sg;  // this lane group's 16 neighbours of the chunk
-                acc = bytemax16(acc, hll_walk_first16(hll_in, nb + bg, deg - bg, hi - bg, i, c));
-            }
-            acc = bytemax16(acc, shfl_xor4(acc, 16));
-            acc = bytemax16(acc, shfl_xor4(acc, 32));
-            if (sg == 0) part_hll[wave][c] = acc;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            if (mh_out && lane < CM) {
-                mh_acc = part_mh[0][lane];
-#pragma unroll
-                for (int w = 1; w < kHubWaves; ++w) mh_acc = min4(mh_acc, part_mh[w][lane]);
-            }
-            if (hll_out && lane >= 32 && lane < 32 + CH) {
-                hll_acc = part_hll[0][lane - 32];
-#pragma unroll
-                for (int w = 1; w < kHubWaves; ++w) hll_acc = bytemax16(hll_acc, part_hll[w][lane - 32]);
-            }
-        }
-    };
-    // wave 0 stores the finished row (+ its cardinality)
-    auto finish = [&](int64_t i, u32x4 mh_acc, u32x4 hll_acc) {
-        if (mh_out && lane < CM) {
-            *reinterpret_cast<u32x4 *>(mh_out + i * P + 4 * lane) = mh_acc;
-            mirror_mh4(g.mir, i * P + 4 * lane, mh_acc);
-        }
-        if (hll_out && lane >= 32 && lane < 32 + CH) {  // lanes 32..47 = one DPP row
-            const int c = lane - 32;
-            *reinterpret_cast<u32x4 *>(hll_out + i * M + 16 * c) = hll_acc;
-            mirror_hll16(g.mir, i * M + 16 * c, hll_acc);
-            if (want_cards) {
-                int nonzero = 0;
-                float hsum = 0.0f;
-                hll_dword_stats(hll_acc.x, nonzero, hsum);
-                hll_dword_stats(hll_acc.y, nonzero, hsum);
-                hll_dword_stats(hll_acc.z, nonzero, hsum);
-                hll_dword_stats(hll_acc.w, nonzero, hsum);
-                nonzero = row16_sum_i(nonzero);
-                hsum = row16_sum_f(hsum);
-                if (c == 0) {
-                    const float card = hll_estimate(est, M - nonzero, hsum);
-                    cards_out[i * cards_stride] = card;
-                    mirror_card(g.mir, i * cards_stride, card);
-                }
-            }
-        }
-    };
-
-    for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
-        const int64_t i = g.hub_rows[h];
-        if (!g.owns(i)) continue;  // workgroup-uniform
-        const int64_t rb = g.rowptr[i];
-        const int deg = (int)(g.rowptr[i + 1] - rb);
-        const int total = deg + (i < n_self ? 1 : 0);
-        u32x4 mh_acc = {0u, 0u, 0u, 0u}, hll_acc = {0u, 0u, 0u, 0u};
-        walk(i, g.col + rb, deg, 0, total, mh_acc, hll_acc);
-        if (wave == 0) finish(i, mh_acc, hll_acc);
-        __syncthreads();
-    }
-
-    // ---- mega rows: every workgroup takes slices of SS_MEGA_SLICE neighbours of every mega row; the partial rows go
-    // through mega_scratch and the workgroup that finishes a row's LAST slice (ticket counter) combines them.  A row
-    // with a million neighbours is spread over the whole chip instead of being one workgroup's serial walk.
-    // The slices of ALL mega rows form one list (slice s of the row with first slice f is global slice f + s) that continues the
-    // round robin of the hub rows above: hub row h went to workgroup h % grid, global slice gs goes to (n_hubs + gs) % grid.
-    // Whose slice gs is: every thread looks at some descriptors (a per-row loop over all mega rows cost every workgroup three
-    // dependent loads per ROW, slices or not).
-    for (int gs = (int)((blockIdx.x + gridDim.x - (unsigned)n_hubs % gridDim.x) % gridDim.x); gs < n_slices; gs += gridDim.x) {
-        for (int t = threadIdx.x; t < n_mega; t += kHubThreads) {
-            const int4 d = reinterpret_cast<const int4 *>(g.mega_rows)[t];
-            if (gs >= d.y && gs < d.y + d.z) s_m = t;
-        }
-        __syncthreads();
-        const int m = s_m;
-        const int4 e = reinterpret_cast<const int4 *>(g.mega_rows)[m];  // {row, first slice, slices, ticket}
-        const int64_t i = e.x;
-        if (!g.owns(i)) { __syncthreads(); continue; }  // workgroup-uniform
-        const int64_t rb = g.rowptr[i];
-        const int deg = (int)(g.rowptr[i + 1] - rb);
-        const int total = deg + (i < n_self ? 1 : 0);
-        {
-            const int sl = gs - e.y;
-            const int lo = sl * SS_MEGA_SLICE < total ? sl * SS_MEGA_SLICE : total;
-            const int hi = lo + SS_MEGA_SLICE < total ? lo + SS_MEGA_SLICE : total;
-            u32x4 mh_acc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hll_acc = {0u, 0u, 0u, 0u};
-            walk(i, g.col + rb, deg, lo, hi, mh_acc, hll_acc);
-            uint8_t *mine = g.mega_scratch + (int64_t)(e.y + sl) * kMegaSlot;
-            if (wave == 0) {
-                if (mh_out && lane < CM) coherent_store4(mine + 16 * lane, mh_acc);
-                if (hll_out && lane >= 32 && lane < 32 + CH) coherent_store4(mine + kMegaHllOffset + 16 * (lane - 32), hll_acc);
-            }
-            publish_drain();  // every wave: the slot stores are acknowledged before the barrier that precedes the ticket
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int prev = take_ticket(&g.mega_rows[4 * m + 3]);
-                s_last = prev == e.z - 1;
-                if (s_last) reset_ticket(&g.mega_rows[4 * m + 3]);  // every slice has arrived: ready for the next hop
-            }
-            __syncthreads();
-            if (s_last) {  // workgroup-uniform.  All 16 waves read the slots (wave w: slots w, w + 16, ...: a row of 70 000
-                           // neighbours has 69 of them, one wave reading them in turn was a 50 us tail), wave 0 combines and stores
-                u32x4 mh_all = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hll_all = {0u, 0u, 0u, 0u};
-                for (int q = wave; q < e.z; q += kHubWaves) {
-                    const uint8_t *part = g.mega_scratch + (int64_t)(e.y + q) * kMegaSlot;
-                    if (mh_out && lane < CM) mh_all = min4(mh_all, coherent_load4(part + 16 * lane));
-                    if (hll_out && lane >= 32 && lane < 32 + CH)
-                        hll_all = bytemax16(hll_all, coherent_load4(part + kMegaHllOffset + 16 * (lane - 32)));
-                }
-                if (mh_out && lane < CM) part_mh[wave][lane] = mh_all;
-                if (hll_out && lane >= 32 && lane < 32 + CH) part_hll[wave][lane - 32] = hll_all;
-                __syncthreads();
-                if (wave == 0) {
-                    if (mh_out && lane < CM) {
-#pragma unroll
-                        for (int w = 1; w < kHubWaves; ++w) mh_all = min4(mh_all, part_mh[w][lane]);
-                    }
-                    if (hll_out && lane >= 32 && lane < 32 + CH) {
-#pragma unroll
-                        for (int w = 1; w < kHubWaves; ++w) hll_all = bytemax16(hll_all, part_hll[w][lane - 32]);
-                    }
-                    finish(i, mh_all, hll_all);
-                }
-            }
-            __syncthreads();
-        }
-    }
+    table_hub_units<kHubWaves, DO_MH, DO_HLL>(g, (int)blockIdx.x, (int)gridDim.x, mh_in, mh_out, hll_in, hll_out, cards_out, cards_stride, est,
+                                              want_cards, hub);
 }
 
 template <int TP, int TM>
@@ -328,44 +204,63 @@ int launch_propagate(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out
     const int rows_per_block = 256 / kWave;
     const int64_t blocks = (g.rows() + rows_per_block - 1) / rows_per_block;
     const bool hubs = TP == 128 && TM == 256 && g.hub_rows && g.hub_count;
+    const int lead = hub_lead_blocks(hubs && !hll_out);  // (the <128, 256> row kernel hosts MinHash units only)
     {
         ProfileSpan span(stream, mh_out && !hll_out && TP == 128 ? SS_PROF_MINHASH_HOP : SS_PROF_TAGS);  // MinHash table hop
-        hipLaunchKernelGGL((propagate_kernel<TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, g, mh_in, mh_out, P, hll_in, hll_out,
-                           M, cards_out, cards_stride, prm, hubs);
+        hipLaunchKernelGGL((propagate_kernel<TP, TM>), dim3((unsigned)(blocks + lead)), dim3(256), 0, stream, g, mh_in, mh_out, P, hll_in,
+                           hll_out, M, cards_out, cards_stride, prm, hubs, lead, (const uint8_t *)nullptr, (uint8_t *)nullptr, (float *)nullptr);
     }
     SS_LAUNCH_CHECK();
-    if (hubs) {
-        hipLaunchKernelGGL(propagate_hub_kernel, dim3(kHubGrid), dim3(kHubThreads), 0, stream, g, mh_in, mh_out, hll_in, hll_out,
-                           cards_out, cards_stride, prm);
-        SS_LAUNCH_CHECK();
-    }
+    if (hubs && lead == 0) return launch_propagate_hub_only(g, mh_in, mh_out, hll_in, hll_out, cards_out, cards_stride, prm, stream);
     return SS_OK;
 }
 
-// the MinHash table hop of the regular rows alone (P = 128), for ss_fused_hop_stage
-int launch_minhash_hop(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, bool skip_hubs, hipStream_t stream)
+// the MinHash table hop alone (P = 128): the regular rows and -- `lead` leading workgroups -- the hub units of the MinHash table
+// and, with hub_hll_out, of the HLL table of the same hop (hub_cards_out / cards_stride / prm: its cardinalities)
+int launch_minhash_hop(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, bool skip_hubs, int lead, const uint8_t *hub_hll_in,
+                       uint8_t *hub_hll_out, float *hub_cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
 {
     ProfileSpan span(stream, SS_PROF_MINHASH_HOP);
-    hipLaunchKernelGGL((propagate_kernel<128, 256>), dim3((unsigned)((g.rows() + 3) / 4)), dim3(256), 0, stream, g, mh_in, mh_out, 128,
-                       (const uint8_t *)nullptr, (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, ss_hll_params{}, skip_hubs);
+    hipLaunchKernelGGL((propagate_kernel<128, 256>), dim3((unsigned)((g.rows() + 3) / 4 + lead)), dim3(256), 0, stream, g, mh_in, mh_out, 128,
+                       (const uint8_t *)nullptr, (uint8_t *)nullptr, 256, (float *)nullptr, cards_stride, prm, skip_hubs, lead, hub_hll_in,
+                       hub_hll_out, hub_cards_out);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
+// the hub units of a table hop as a launch of their own (16-wave workgroups): what the row launches above did not host
 int launch_propagate_hub_only(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, const uint8_t *hll_in, uint8_t *hll_out,
                               float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
 {
-    if (!g.hub_rows || !g.hub_count) return SS_OK;
+    if (!g.hub_rows || !g.hub_count || (!mh_out && !hll_out)) return SS_OK;
     ProfileSpan span(stream, SS_PROF_HUB);
-    hipLaunchKernelGGL(propagate_hub_kernel, dim3(kHubGrid), dim3(kHubThreads), 0, stream, g, mh_in, mh_out, hll_in, hll_out, cards_out,
-                       cards_stride, prm);
+    if (mh_out && hll_out)
+        hipLaunchKernelGGL((propagate_hub_kernel<true, true>), dim3(kHubGrid), dim3(kHubThreads), 0, stream, g, mh_in, mh_out, hll_in, hll_out,
+                           cards_out, cards_stride, prm);
+    else if (mh_out)
+        hipLaunchKernelGGL((propagate_hub_kernel<true, false>), dim3(kHubGrid), dim3(kHubThreads), 0, stream, g, mh_in, mh_out, hll_in, hll_out,
+                           cards_out, cards_stride, prm);
+    else
+        hipLaunchKernelGGL((propagate_hub_kernel<false, true>), dim3(kHubGrid), dim3(kHubThreads), 0, stream, g, mh_in, mh_out, hll_in, hll_out,
+                           cards_out, cards_stride, prm);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+}
+
+// the HLL table hop alone (M = 256): 4 destinations per wavefront + the hub units of the HLL table
+static int launch_hll_hop(const GraphArgs &g, const uint8_t *hll_in, uint8_t *hll_out, float *cards_out, int64_t cards_stride,
+                          const ss_hll_params &prm, bool hubs, int lead, hipStream_t stream)
+{
+    ProfileSpan span(stream, SS_PROF_HLL_HOP);
+    hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((g.rows() + 15) / 16 + lead)), dim3(256), 0, stream, g, hll_in, hll_out,
+                       cards_out, cards_stride, prm, hubs, lead);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
 
 }  // namespace ss
 
-// MinHash table hop of the listed rows only (+ the hub pass, which always serves every hub row)
+// MinHash table hop of the listed rows only (+ the hub units, which always cover every hub row)
 extern "C" int ss_minhash_hop_rows(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_out, int32_t P, const int64_t *rows,
                                    int64_t n_rows, void *stream)
 {
@@ -381,19 +276,22 @@ extern "C" int ss_minhash_hop_rows(const ss_csr_graph *graph, const uint32_t *mh
     g.row_list = rows;
     g.n_list = n_rows;
     hipStream_t s = (hipStream_t)stream;
-    const bool hubs = P == 128 && g.hub_rows && g.hub_count;  // (the hub pass of the table hops is P = 128 only, as in ss_propagate)
-    const unsigned blocks = (unsigned)((n_rows + 3) / 4);
+    const bool hubs = P == 128 && g.hub_rows && g.hub_count;  // (the hub units of the table hops are P = 128 only, as in ss_propagate)
+    const int lead = hub_lead_blocks(hubs);
+    const unsigned blocks = (unsigned)((n_rows + 3) / 4 + lead);
     {
         ProfileSpan span(s, SS_PROF_MINHASH_ROWS);
         if (P == 128)
             hipLaunchKernelGGL((propagate_kernel<128, 256>), dim3(blocks), dim3(256), 0, s, g, mh_in, mh_out, 128, (const uint8_t *)nullptr,
-                               (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, ss_hll_params{}, hubs);
+                               (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, ss_hll_params{}, hubs, lead, (const uint8_t *)nullptr,
+                               (uint8_t *)nullptr, (float *)nullptr);
         else
             hipLaunchKernelGGL((propagate_kernel<0, 0>), dim3(blocks), dim3(256), 0, s, g, mh_in, mh_out, P, (const uint8_t *)nullptr,
-                               (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, ss_hll_params{}, false);
+                               (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, ss_hll_params{}, false, 0, (const uint8_t *)nullptr,
+                               (uint8_t *)nullptr, (float *)nullptr);
     }
     SS_LAUNCH_CHECK();
-    if (!hubs) return SS_OK;
+    if (!hubs || lead > 0) return SS_OK;
     GraphArgs all = to_args(*graph);
     return launch_propagate_hub_only(all, mh_in, mh_out, nullptr, nullptr, nullptr, 0, ss_hll_params{}, s);
 }
@@ -423,39 +321,27 @@ extern "C" int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, ui
     }
     const GraphArgs g = to_args(*graph);
     if (g.rows() == 0) return SS_OK;
-    const int64_t R = g.rows();
+    hipStream_t s = (hipStream_t)stream;
+    const bool hubs = g.hub_rows && g.hub_count;
+    const int lead = hub_lead_blocks(hubs);
     if (!mh_out && M == 256) {  // HLL alone: 4 destinations per wavefront
-        const bool hubs = g.hub_rows && g.hub_count;
-        {
-            ProfileSpan span((hipStream_t)stream, SS_PROF_HLL_HOP);
-            hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, g, hll_in,
-                               hll_out, cards_out, cards_stride, p0, hubs);
-        }
-        SS_LAUNCH_CHECK();
-        return launch_propagate_hub_only(g, nullptr, nullptr, hll_in, hll_out, cards_out, cards_stride, p0, (hipStream_t)stream);
+        const int rc = launch_hll_hop(g, hll_in, hll_out, cards_out, cards_stride, p0, hubs, lead, s);
+        if (rc != SS_OK || lead > 0) return rc;
+        return launch_propagate_hub_only(g, nullptr, nullptr, hll_in, hll_out, cards_out, cards_stride, p0, s);
     }
     if (mh_out && hll_out && P == 128 && M == 256) {
         // both sketches: one launch per sketch is faster than the two-sketch kernel (192 + 111 us vs 326 us on the bench
-        // graph): the HLL kernel keeps 4 destinations in flight per wavefront, the MinHash kernel one; a single hub pass
-        // serves both
-        const bool hubs = g.hub_rows && g.hub_count;
-        {
-            ProfileSpan span((hipStream_t)stream, SS_PROF_HLL_HOP);
-            hipLaunchKernelGGL(hll_propagate_row16_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, g, hll_in,
-                               hll_out, cards_out, cards_stride, p0, hubs);
-        }
-        SS_LAUNCH_CHECK();
-        {
-            ProfileSpan span((hipStream_t)stream, SS_PROF_MINHASH_HOP);
-            hipLaunchKernelGGL((propagate_kernel<128, 256>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, mh_in,
-                               mh_out, 128, (const uint8_t *)nullptr, (uint8_t *)nullptr, 256, (float *)nullptr, (int64_t)0, p0, hubs);
-        }
-        SS_LAUNCH_CHECK();
-        return launch_propagate_hub_only(g, mh_in, mh_out, hll_in, hll_out, cards_out, cards_stride, p0, (hipStream_t)stream);
+        // graph): the HLL kernel keeps 4 destinations in flight per wavefront, the MinHash kernel one; each launch hosts the hub
+        // units of its own sketch
+        int rc = launch_hll_hop(g, hll_in, hll_out, cards_out, cards_stride, p0, hubs, lead, s);
+        if (rc != SS_OK) return rc;
+        rc = launch_minhash_hop(g, mh_in, mh_out, hubs, lead, nullptr, nullptr, nullptr, 0, p0, s);
+        if (rc != SS_OK || lead > 0) return rc;
+        return launch_propagate_hub_only(g, mh_in, mh_out, hll_in, hll_out, cards_out, cards_stride, p0, s);
     }
     // the fast path needs both sketches (or the absent one's size irrelevant): P == 128 and M == 256
     const bool fast = (!mh_out || P == 128) && (!hll_out || M == 256);
     if (fast)
-        return launch_propagate<128, 256>(g, mh_in, mh_out, 128, hll_in, hll_out, 256, cards_out, cards_stride, p0, (hipStream_t)stream);
-    return launch_propagate<0, 0>(g, mh_in, mh_out, P, hll_in, hll_out, M, cards_out, cards_stride, p0, (hipStream_t)stream);
+        return launch_propagate<128, 256>(g, mh_in, mh_out, 128, hll_in, hll_out, 256, cards_out, cards_stride, p0, s);
+    return launch_propagate<0, 0>(g, mh_in, mh_out, P, hll_in, hll_out, M, cards_out, cards_stride, p0, s);
 }

@@ -608,13 +608,14 @@ __device__ __forceinline__ void hll_hop_row16(const GraphArgs &g, int64_t row, b
     hll_row16_finish(i, ok && !hub, nb, deg, total, acc, 16, hll_in, hll_out, cards_out, cards_stride, est, want_cards, c, g.mir);
 }
 
-// hub-row-only launches (defined in ss_first_hop.hip / ss_propagate.hip) for kernels that skip hub rows themselves
+// launches defined in ss_first_hop.hip / ss_propagate.hip that ss_fused_hop_stage strings together (`lead`, `skip_hubs`: ss_hub.hpp)
 int launch_first_hop_hub_only(const GraphArgs &g, const uint64_t *a, const uint64_t *b, int P, uint32_t *mh_out, int p, uint8_t *hll_out,
                               float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream);
 int launch_propagate_hub_only(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, const uint8_t *hll_in, uint8_t *hll_out,
                               float *cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream);
-int launch_minhash_hop(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, bool skip_hubs, hipStream_t stream);
+int launch_minhash_hop(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, bool skip_hubs, int lead, const uint8_t *hub_hll_in,
+                       uint8_t *hub_hll_out, float *hub_cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream);
 int launch_hll_first_hop_rows(const GraphArgs &g, int p, uint8_t *hll_out, float *cards_out, int64_t cards_stride, const ss_hll_params &prm,
-                              bool skip_hubs, hipStream_t stream);
+                              bool skip_hubs, int lead, const uint64_t *a, const uint64_t *b, uint32_t *hub_mh_out, int P, hipStream_t stream);
 
 }  // namespace ss

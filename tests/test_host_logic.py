@@ -282,7 +282,7 @@ def test_byte_model_of_the_step(ssa):
     eh_, nh_ = rf.hub_split(deg, 144)
     assert (eh_, nh_) == (50 * 20000, 50)
     e2 = int(deg.sum())
-    ks = rf.kernel_bytes(n, e2, 128, 8, 2, 65536, eh_, nh_)
+    ks = rf.kernel_bytes(n, e2, 128, 8, 2, 65536, eh_, nh_, hosted=False)  # hub units as launches of their own (rounds 1-3)
     k0 = rf.kernel_bytes(n, e2, 128, 8, 2, 65536)
     assert ks['minhash_hop'] == (e2 - eh_ + 2 * (n - nh_)) * 512 + 4 * (e2 - eh_) + 8 * (n + 1) < k0['minhash_hop']
     assert k0['hub_table_hop'] == 0 and k0['hub_first_hop'] == 0
@@ -292,6 +292,17 @@ def test_byte_model_of_the_step(ssa):
     # it also reads its list entry and both rowptr words)
     assert abs(moved - 4 * eh_ - ks['hub_table_hop']) <= 32 * nh_
     assert abs(rf.step_bytes_implemented(n, e2, 128, 8, 2, 65536, eh_, nh_) + 8 * eh_ - rf.step_bytes_implemented(n, e2, 128, 8, 2, 65536)) <= 64 * nh_
+    # hub units hosted by the row launches (round 4, the default): no hub family, the hosting launches carry the hub rows' bytes --
+    # the HLL first-hop launch both hop-1 tables, the MinHash table hop both hop-2 tables; the fused kernel hosts none
+    kh = rf.kernel_bytes(n, e2, 128, 8, 2, 65536, eh_, nh_)
+    assert kh['hub_table_hop'] == 0 and kh['hub_first_hop'] == 0
+    assert kh['fused_first_hop_hll_hop'] == ks['fused_first_hop_hll_hop'] and kh['first_hop_minhash'] == ks['first_hop_minhash']
+    assert kh['minhash_hop'] - ks['minhash_hop'] == ks['hub_table_hop'] + 4 * eh_ + 24 * nh_ + 4 * nh_  # + a second pass over the ids, cards
+    assert kh['first_hop_hll'] - ks['first_hop_hll'] == ks['hub_first_hop'] + 4 * eh_ + 24 * nh_ + 4 * nh_
+    k3, s3 = rf.kernel_bytes(n, e2, 128, 8, 3, 65536, eh_, nh_), rf.kernel_bytes(n, e2, 128, 8, 3, 65536, eh_, nh_, hosted=False)
+    later = 4 * eh_ + 24 * nh_ + (eh_ + 2 * nh_) * 512          # hops >= 3: the MinHash launch hosts the MinHash units alone
+    assert k3['minhash_hop'] - s3['minhash_hop'] == ((kh['minhash_hop'] - ks['minhash_hop']) + later) // 2  # mean over the two launches
+    assert k3['hll_hop'] - s3['hll_hop'] == 4 * eh_ + 24 * nh_ + (eh_ + 2 * nh_) * 256 + 4 * nh_
     # residency as a fraction: the label is a threshold, the number is what to read
     assert rf.cache_resident_fraction(rf.gathered_table_bytes(n, 'minhash_hop')) == 1.0
     assert abs(rf.cache_resident_fraction(rf.gathered_table_bytes(576289, 'minhash_hop')) - 0.9097) < 1e-3

@@ -35,7 +35,7 @@ def main():
         kind = sys.argv[sys.argv.index('--graph') + 1]
         alpha = float(sys.argv[sys.argv.index('--alpha') + 1]) if '--alpha' in sys.argv else 0.5
         hub_e, hub_n = bench.hub_stats(ssa, bench.synthetic_graph(n, cfg['e_und'], kind, alpha), n)
-    model = rf.kernel_bytes(n, e, 128, 8, h, b, hub_e, hub_n)
+    model = rf.kernel_bytes(n, e, 128, 8, h, b, hub_e, hub_n, bench.HUB_UNITS_HOSTED)
     stats = {r['Name']: r for r in csv.DictReader(l for l in open(os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats.csv')) if not l.startswith('#'))}
     pmc_path = os.path.join(ROOT, 'profiles', f'{tag}_pmc.json')
     pmc = json.load(open(pmc_path))['raw'] if os.path.exists(pmc_path) else {}
