@@ -18,7 +18,7 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 dev = torch.device('cuda:0')
 n, e_und, B = bench.N_NODES, bench.E_UND, bench.BATCH
 bad = 0
-for kind, alpha, h in (('uniform', 0.5, 2), ('powerlaw', 0.9, 2), ('uniform', 0.5, 3)):
+for kind, alpha, h in (('uniform', 0.5, 2), ('powerlaw', 0.9, 2), ('uniform', 0.5, 3), ('powerlaw', 0.5, 2), ('powerlaw', 0.9, 3)):
     ei = torch.from_numpy(bench.synthetic_graph(n, e_und, kind, alpha)).to(dev)
     links = torch.from_numpy(bench.synthetic_links(n, B, 2)).to(dev)
     eh = ssa.ElphHashes(Namespace(max_hash_hops=h, hll_p=8, minhash_num_perm=128, floor_sf=False, use_zero_one=True))
