@@ -166,9 +166,15 @@ def roofline_numbers(rf, bytes_alg, launch_ms, table_bytes, traffic):
         basis, note = traffic['bytes_per_launch'], f"fabric bytes of the PMC passes ({traffic['file']}): fewer than the algorithmic bytes, repeats served by the L2"
     achieved = basis / (launch_ms * 1e-3) / 1e9
     ceiling = rf.gather_ceiling_gbs(table_bytes)
-    return {'achieved_gbs': achieved, 'frac_of_hbm_peak': achieved / rf.HBM_PEAK_GBS, 'bytes_basis': note,
-            'ceiling_gbs': ceiling, 'frac_of_ceiling': achieved / ceiling,
-            'ceiling_note': 'random 512-byte-row gathers from a table of this size, tools/micro/gather_ceiling.hip (profiles/round4_gather_ceiling.txt)'}
+    out = {'achieved_gbs': achieved, 'frac_of_hbm_peak': achieved / rf.HBM_PEAK_GBS, 'bytes_basis': note,
+           'ceiling_gbs': ceiling, 'frac_of_ceiling': min(1.0, achieved / ceiling),
+           'ceiling_note': 'random 512-byte-row gathers from a table of this size, tools/micro/gather_ceiling.hip (profiles/round4_gather_ceiling.txt)'}
+    if achieved > ceiling:
+        # the micro-benchmark moves nothing but gathered rows; a kernel also streams ids in and finished rows out, which travel faster
+        # than gathers -- its overall rate can pass the pure-gather figure by a few per cent (seen at ogbl-ppa size: 7.7 vs 7.65 TB/s)
+        out['ceiling_exceeded_by'] = achieved / ceiling - 1.0
+        out['ceiling_note'] += '; the kernel\'s overall rate is ABOVE it (its sequential streams -- ids, output rows -- move faster than gathers): fraction reported as 1'
+    return out
 
 
 # the rows above the hub threshold are walked as hub units by leading workgroups of the row launches (csrc/ss_hub.hpp); SS_HUB_LAUNCHES=1
@@ -267,6 +273,7 @@ def secondary_case(ssa, dev, name, config, graph='uniform', alpha=0.5, api='buil
             'dominant_algorithmic_bytes': bytes_, 'dominant_traffic_bytes': traffic['bytes_per_launch'] if traffic else None,
             'dominant_frac_of_hbm_peak': frac, 'dominant_bytes_basis': roof.get('bytes_basis'),
             'ceiling_gbs': roof.get('ceiling_gbs'), 'dominant_frac_of_ceiling': roof.get('frac_of_ceiling'),
+            **({'ceiling_exceeded_by': roof['ceiling_exceeded_by'], 'ceiling_note': roof['ceiling_note']} if 'ceiling_exceeded_by' in roof else {}),
             'hub_rows': hub_n, 'hub_edge_share': hub_e / e_dir,
             'resident': 'infinity-cache' if table_bytes <= rf.INFINITY_CACHE_BYTES else 'hbm',
             'cache_resident_fraction': rf.cache_resident_fraction(table_bytes),
@@ -623,7 +630,7 @@ def main():
                      # of re-reads, it is not an HBM-only byte count
                      'traffic': traffic['bytes_per_launch'] if traffic else None, 'traffic_file': traffic['file'] if traffic else None,
                      'bytes_basis': roof.get('bytes_basis'), 'ceiling_gbs': roof.get('ceiling_gbs'), 'frac_of_ceiling': roof.get('frac_of_ceiling'),
-                     'ceiling_note': roof.get('ceiling_note'),
+                     'ceiling_note': roof.get('ceiling_note'), **({'ceiling_exceeded_by': roof['ceiling_exceeded_by']} if 'ceiling_exceeded_by' in roof else {}),
                      'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n,
                      'resident': 'infinity-cache' if table_bytes <= rf.INFINITY_CACHE_BYTES else 'hbm',
                      'cache_resident_fraction': rf.cache_resident_fraction(table_bytes),
