@@ -43,7 +43,7 @@ for rep in range(6):
     t0 = v[8]
     rel = {name: (v[i] - t0) / 100.0 if v[i] else None for i, name in
            ((15, 'last bucket workgroup decided'), (14, 'last dense bucket registered'), (9, 'last ordinary bucket done'),
-            (10, 'last helper past the bucket-sum barrier'), (11, 'last helper counted'), (12, 'last helper past the counter barrier'),
+            (10, 'last helper saw every bucket arrive'), (11, 'last helper counted'), (12, 'last helper past the counter barrier'),
             (13, 'last helper placed'))}
     lines.append(rel)
     if rep == 5:
