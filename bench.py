@@ -353,6 +353,10 @@ def main():
     # 0.4484 / 0.4485 (clocks and caches settled; the timed region is still only 90 ms)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--time-every', type=int, default=4, help='HIP events around every n-th launch of the dominant kernel inside the timed region')
+    ap.add_argument('--settle-seconds', type=float, default=2.0,
+                    help='run the step untimed for this long BEFORE the warm-up steps: a fresh process finds the GPU at idle clocks, and a few '
+                         'milliseconds of warm-up do not bring it to the state every later step of a job runs in (reported in the line)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--config', default='collab', choices=sorted(CONFIGS), help='synthetic shape (default: BASELINE configs[1])')
     ap.add_argument('--graph', default='uniform', choices=['uniform', 'powerlaw', 'local'])
@@ -499,6 +503,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # steady state first: clocks, caches, allocator pools and the hub hint of this shape (disclosed as `settle_seconds`; not timed)
+    settle_steps = 0
+    if a.settle_seconds > 0:
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < a.settle_seconds:
+            for _ in range(10):
+                feats = step()
+            settle_steps += 10
+            torch.cuda.synchronize(dev)
     for _ in range(a.warmup):
         feats = step()
     # HIP events around every launch of the dominant kernel, on its stream.  ELPH call sequence at h = 2 with the deferred table hop:
@@ -507,7 +520,9 @@ def main():
     dom_tag = nat.PROF_FUSED if (elph_rows_only and h == 2) else nat.PROF_MINHASH_HOP
     if a.api == 'buddy':  # the link set dwarfs the build: the query is the dominant kernel (92 % of a citation2-size precompute)
         dom_tag = nat.PROF_PAIRS
-    lib.ss_profile_enable(1 << dom_tag)
+    # (every 4th launch of it: a timed launch costs its step ~5 us -- the completion signal its events are filled from --, 1 % of the step)
+    lib.ss_profile_sample(a.time_every)
+    lib.ss_profile_enable(0 if os.environ.get('SS_BENCH_EXP_NO_EVENTS') else 1 << dom_tag)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -517,6 +532,7 @@ def main():
     dom_ms, dom_n = c_float(), c_int32()
     lib.ss_profile_read(dom_tag, byref(dom_ms), byref(dom_n))  # the launches of the timed region only
     lib.ss_profile_enable(0)
+    lib.ss_profile_sample(1)
     if launched:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -606,7 +622,7 @@ def main():
     out = {
         'metric': 'edge-pairs/sec subgraph-feature extraction (build+query)',
         'value': pairs_per_step * a.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps,
-        'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': a.scaling,
+        'warmup': a.warmup, 'settle_seconds': a.settle_seconds, 'settle_steps': settle_steps, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': a.scaling,
         'vs_baseline': None, 'dtype': 'u32/u8 sketches, f32 estimator', 'data': 'synthetic',
         'config': {'workload': f'ogbl-{a.config}-like synthetic {a.graph} graph' + (' (BASELINE configs[1])' if a.config == 'collab' else '') +
                                ', BUDDY/ELPH hot path: step = build_hash_tables + get_subgraph_features, nothing cached across steps; '
@@ -631,7 +647,7 @@ def main():
                      'traffic': traffic['bytes_per_launch'] if traffic else None, 'traffic_file': traffic['file'] if traffic else None,
                      'bytes_basis': roof.get('bytes_basis'), 'ceiling_gbs': roof.get('ceiling_gbs'), 'frac_of_ceiling': roof.get('frac_of_ceiling'),
                      'ceiling_note': roof.get('ceiling_note'), **({'ceiling_exceeded_by': roof['ceiling_exceeded_by']} if 'ceiling_exceeded_by' in roof else {}),
-                     'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n,
+                     'algorithmic_bytes_per_launch': prop_bytes, 'mean_launch_ms': prop_ms, 'launches_timed': prop_n, 'launches_timed_every': a.time_every,
                      'resident': 'infinity-cache' if table_bytes <= rf.INFINITY_CACHE_BYTES else 'hbm',
                      'cache_resident_fraction': rf.cache_resident_fraction(table_bytes),
                      'hub_rows': hub_n, 'hub_edge_share': hub_e / e_dir,

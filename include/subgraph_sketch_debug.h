@@ -35,6 +35,9 @@ int ss_profile_enable(uint32_t tag_mask);   /* bit t enables family t; 0 disable
  * SS_PROF_HUB span) or as launches of their own; reset != 0 returns the count and clears it.  For the tests of the hub hints. */
 int64_t ss_debug_hub_calls(int32_t reset);
 int ss_profile_read(int32_t tag, float *mean_ms_out, int32_t *launches_out);
+/* Time only every `every`-th launch of an enabled family (the first after ss_profile_enable, then each `every`-th): a timed launch costs
+ * its step about 5 us (the completion signal the events are filled from), which is 1 % of the step bench.py times.  Default 1. */
+int ss_profile_sample(int32_t every);
 
 /* Launch-duration probe for bench.py: records HIP events around `reps` back-to-back launches of the
  * same ss_propagate / ss_pair_features call ON `stream` and returns the mean milliseconds per launch in

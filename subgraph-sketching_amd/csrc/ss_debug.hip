@@ -19,26 +19,30 @@ struct Span {
 };
 std::vector<Span> g_spans;
 std::atomic<int64_t> g_hub_calls{0};
+std::atomic<uint32_t> g_every{1};                 // ss_profile_sample: every n-th launch of an enabled family is timed
+std::atomic<uint32_t> g_seen[SS_PROF_TAGS] = {};  // launches of each family since the last ss_profile_enable
 }  // namespace
 
 void note_hub_call() { g_hub_calls.fetch_add(1, std::memory_order_relaxed); }
 
-ProfileSpan::ProfileSpan(hipStream_t s, int tag_) : stream(s), tag(tag_)
+ProfileSpan::ProfileSpan(hipStream_t s, int tag_, bool attached_) : stream(s), tag(tag_), attached(attached_)
 {
     if (tag < 0 || tag >= SS_PROF_TAGS || !((g_mask.load(std::memory_order_relaxed) >> tag) & 1u)) return;
+    const uint32_t every = g_every.load(std::memory_order_relaxed);
+    if (every > 1 && g_seen[tag].fetch_add(1, std::memory_order_relaxed) % every != 0) return;  // (the 1st, (n+1)-th, ... launch)
     {
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_spans.size() >= (size_t)SS_PROFILE_MAX_EVENTS) return;
     }
     if (hipEventCreate(&start) != hipSuccess) { start = nullptr; return; }
     if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start); start = nullptr; return; }
-    (void)hipEventRecord(start, stream);
+    if (!attached) (void)hipEventRecord(start, stream);
 }
 
 ProfileSpan::~ProfileSpan()
 {
     if (!start) return;
-    (void)hipEventRecord(stop, stream);
+    if (!attached) (void)hipEventRecord(stop, stream);
     std::lock_guard<std::mutex> lock(g_mutex);
     g_spans.push_back(Span{start, stop, tag});
 }
@@ -53,6 +57,14 @@ extern "C" int64_t ss_debug_hub_calls(int32_t reset)
 extern "C" int ss_profile_enable(uint32_t tag_mask)
 {
     ss::g_mask.store(tag_mask, std::memory_order_relaxed);
+    for (auto &c : ss::g_seen) c.store(0, std::memory_order_relaxed);
+    return SS_OK;
+}
+
+extern "C" int ss_profile_sample(int32_t every)
+{
+    if (every < 1) return SS_ERR_INVALID_ARG;
+    ss::g_every.store((uint32_t)every, std::memory_order_relaxed);
     return SS_OK;
 }
 

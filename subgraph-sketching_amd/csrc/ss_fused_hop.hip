@@ -266,12 +266,12 @@ extern "C" int ss_fused_hop_stage(const ss_csr_graph *graph, const uint64_t *a, 
                           : (blocks > 256u * 128u ? 64 : 20);
     const unsigned grid = blocks < (unsigned)(256 * wg_per_cu) ? blocks : (unsigned)(256 * wg_per_cu);
     {
-        ProfileSpan span(s, SS_PROF_FUSED);
+        ProfileSpan span(s, SS_PROF_FUSED, true);
         switch (P / kWave) {
-            case 1: hipLaunchKernelGGL((fused_hop_persistent_kernel<1>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-            case 2: hipLaunchKernelGGL((fused_hop_persistent_kernel<2>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-            case 3: hipLaunchKernelGGL((fused_hop_persistent_kernel<3>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
-            default: hipLaunchKernelGGL((fused_hop_persistent_kernel<4>), dim3(grid), dim3(256), 0, s, g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+            case 1: span.launch(fused_hop_persistent_kernel<1>, dim3(grid), dim3(256), g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+            case 2: span.launch(fused_hop_persistent_kernel<2>, dim3(grid), dim3(256), g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+            case 3: span.launch(fused_hop_persistent_kernel<3>, dim3(grid), dim3(256), g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
+            default: span.launch(fused_hop_persistent_kernel<4>, dim3(grid), dim3(256), g, a, b, mh1_out, p, hll1_in, hll2_out, cards2_out, cards_stride, p0, hubs); break;
         }
     }
     SS_LAUNCH_CHECK();

@@ -528,13 +528,13 @@ int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &t
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     {
-        ProfileSpan span(stream, SS_PROF_PAIRS);
+        ProfileSpan span(stream, SS_PROF_PAIRS, true);
         if (grouped && TP == 128 && H >= 2)  // (the default sketch shape only: one more instantiation per hop count)
-            hipLaunchKernelGGL((pair_features_kernel<H, TP, TM, (TP == 128 && H >= 2)>), dim3((unsigned)blocks), dim3(256), 0, stream, links, B, N,
-                               tabs, P, M, cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees, order);
+            span.launch(pair_features_kernel<H, TP, TM, (TP == 128 && H >= 2)>, dim3((unsigned)blocks), dim3(256), links, B, N, tabs, P, M, cards,
+                        cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees, order);
         else
-            hipLaunchKernelGGL((pair_features_kernel<H, TP, TM>), dim3((unsigned)blocks), dim3(256), 0, stream, links, B, N, tabs, P, M,
-                               cards, cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees, order);
+            span.launch(pair_features_kernel<H, TP, TM>, dim3((unsigned)blocks), dim3(256), links, B, N, tabs, P, M, cards, cards_stride, prm,
+                        flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees, order);
     }
     SS_LAUNCH_CHECK();
     return SS_OK;

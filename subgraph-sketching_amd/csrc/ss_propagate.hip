@@ -220,10 +220,10 @@ int launch_propagate(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out
 int launch_minhash_hop(const GraphArgs &g, const uint32_t *mh_in, uint32_t *mh_out, bool skip_hubs, int lead, const uint8_t *hub_hll_in,
                        uint8_t *hub_hll_out, float *hub_cards_out, int64_t cards_stride, const ss_hll_params &prm, hipStream_t stream)
 {
-    ProfileSpan span(stream, SS_PROF_MINHASH_HOP);
-    hipLaunchKernelGGL((propagate_kernel<128, 256>), dim3((unsigned)((g.rows() + 3) / 4 + lead)), dim3(256), 0, stream, g, mh_in, mh_out, 128,
-                       (const uint8_t *)nullptr, (uint8_t *)nullptr, 256, (float *)nullptr, cards_stride, prm, skip_hubs, lead, hub_hll_in,
-                       hub_hll_out, hub_cards_out);
+    ProfileSpan span(stream, SS_PROF_MINHASH_HOP, true);
+    span.launch(propagate_kernel<128, 256>, dim3((unsigned)((g.rows() + 3) / 4 + lead)), dim3(256), g, mh_in, mh_out, 128,
+                (const uint8_t *)nullptr, (uint8_t *)nullptr, 256, (float *)nullptr, cards_stride, prm, skip_hubs, lead, hub_hll_in, hub_hll_out,
+                hub_cards_out);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
