@@ -507,11 +507,18 @@ def main():
     settle_steps = 0
     if a.settle_seconds > 0:
         t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < a.settle_seconds:
+        while True:
             for _ in range(10):
                 feats = step()
             settle_steps += 10
             torch.cuda.synchronize(dev)
+            go = time.perf_counter() - t_settle < a.settle_seconds
+            if launched:  # every rank runs the SAME number of steps (a step holds collectives): continue while any rank's clock says so
+                flag = torch.tensor([1.0 if go else 0.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                go = bool(flag.item() > 0)
+            if not go:
+                break
     for _ in range(a.warmup):
         feats = step()
     # HIP events around every launch of the dominant kernel, on its stream.  ELPH call sequence at h = 2 with the deferred table hop:
