@@ -88,6 +88,7 @@ SIGNATURES = {
     'ss_profile_enable': (c_int32, [c_uint32]),
     'ss_profile_sample': (c_int32, [c_int32]),
     'ss_debug_hub_calls': (c_int64, [c_int32]),
+    'ss_debug_csr_helpers': (c_int32, [c_void_p]),
     'ss_profile_read': (c_int32, [c_int32, POINTER(c_float), POINTER(c_int32)]),
     'ss_time_propagate': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p,
                                     c_void_p, c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int32,

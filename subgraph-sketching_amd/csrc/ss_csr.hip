@@ -1474,7 +1474,35 @@ int helper_budget(Kernel kernel)
     return (int)(h > 0 ? h : 0);
 }
 
-inline int run_helpers(bool packed)
+// fewer CUs than the device has, for this process or this stream?  The helpers' bound (a quarter of the workgroups the WHOLE device
+// can hold) means nothing then, and a helper that waits for helpers that cannot become resident waits for ever: such launches take
+// the stand-alone dense steps.  The global masks are environment variables of the runtime; a stream's own mask
+// (hipExtStreamCreateWithCUMask) is asked of the stream -- one entry remembered per thread, builds mostly stay on one stream.
+inline bool cu_masked(hipStream_t stream, int dev)
+{
+    static const bool global_mask = getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK");
+    if (global_mask) return true;
+    thread_local hipStream_t last_stream = nullptr;
+    thread_local int last_dev = -1;
+    thread_local bool last_masked = false;
+    if (last_dev == dev && last_stream == stream) return last_masked;
+    bool masked = false;
+    hipDeviceProp_t prop;
+    uint32_t mask[32] = {};  // 1 024 CUs
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && hipExtStreamGetCUMask(stream, 32, mask) == hipSuccess) {
+        int bits = 0;
+        for (uint32_t w : mask) bits += __builtin_popcount(w);
+        masked = bits > 0 && bits < prop.multiProcessorCount;  // (no bit set: the runtime reports no mask at all)
+    } else {
+        (void)hipGetLastError();  // unknown: keep the helpers, as before
+    }
+    last_stream = stream;
+    last_dev = dev;
+    last_masked = masked;
+    return masked;
+}
+
+inline int run_helpers(bool packed, hipStream_t stream)
 {
     static const bool launches = getenv("SS_CSR_DENSE") && !strcmp(getenv("SS_CSR_DENSE"), "launch");
     // per device: a process may drive GPUs of different sizes.  0 = not computed yet (a device whose budget IS 0 recomputes it
@@ -1483,6 +1511,7 @@ inline int run_helpers(bool packed)
     static std::atomic<int> cache[2][64];
     int dev = 0;
     if (launches || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cu_masked(stream, dev)) return 0;
     int h = cache[packed][dev].load(std::memory_order_relaxed);
     if (h == 0) {
         h = packed ? helper_budget(finish_runs_kernel<true>) : helper_budget(finish_runs_kernel<false>);
@@ -1492,6 +1521,9 @@ inline int run_helpers(bool packed)
 }
 
 }  // namespace ss
+
+// (subgraph_sketch_debug.h) helper workgroups a one-level build launched on `stream` would append to its finish launch
+extern "C" int ss_debug_csr_helpers(void *stream) { return ss::run_helpers(true, (hipStream_t)stream); }
 
 #ifdef SS_CSR_TIMING
 extern "C" int ss_csr_timing_read(unsigned long long *out16, int reset)
@@ -1590,7 +1622,7 @@ static int csr_build_launch(const ss::LevelPlan &lp, const int64_t *src, const i
     const unsigned dense_grid = (unsigned)(share_cap < kDenseGrid ? share_cap : kDenseGrid);
     // one-level plans (collab size and below: tens of microseconds per build) run the dense steps by helper workgroups of the finish
     // launch; larger builds by two launches of their own (~9 us of a build of hundreds when they find nothing to do)
-    int helpers = lp.levels == 1 ? run_helpers(packed) : 0;
+    int helpers = lp.levels == 1 ? run_helpers(packed, stream) : 0;
     if ((int64_t)helpers > share_cap) helpers = (int)share_cap;
     const DenseRunArgs dense = {w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, w.dense_share_lo, nullptr, nullptr, 0, 0, helpers};
     const DenseRunWork work = {par, in, lp.node_shift, lp.src_bits, N, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, col};
