@@ -102,12 +102,14 @@ typedef struct ss_csr_graph {
     uint32_t *mirror_mh[7];           /* SS_MAX_MIRRORS */
     uint8_t *mirror_hll[7];
     float *mirror_cards[7];
-    /* Hub-row report (nullable): the first-hop kernels of ss_first_hop / ss_fused_hop_stage store *report_hub_count +         */
-    /* report_mega_count[0] -- the counters ss_csr_build left on the device -- into *hub_report, a device-VISIBLE int32 such as */
-    /* pinned host memory, at their very start (the store is long complete when the launch ends).  The host may read the word   */
-    /* later WITHOUT synchronising, as a hint: a shape whose earlier build listed no such rows is propagated with hub_rows =    */
-    /* NULL -- no hub passes are launched (two per hop that find nothing to do on an unskewed graph), every row is walked by    */
-    /* its row kernel, so a stale hint costs time, never correctness.                                                          */
+    /* Hub-row report (nullable): the first-hop launches from node ids -- the HLL first-hop kernel and the MinHash rows kernel   */
+    /* of ss_first_hop, the HLL first-hop launch of ss_fused_hop_stage (not its fused kernel: a stage called with cards1_out ==  */
+    /* NULL, the deferred first hop, reports nothing) -- store *report_hub_count + report_mega_count[0], the counters            */
+    /* ss_csr_build left on the device, into *hub_report, a device-VISIBLE int32 such as pinned host memory, at their very start */
+    /* (the store is long complete when the launch ends).  The word must stay valid until those launches have run.  The host    */
+    /* may read it later WITHOUT synchronising, as a hint: a shape whose earlier build listed no such rows is propagated with    */
+    /* hub_rows = NULL -- no hub units are served (leading workgroups that find nothing to do on an unskewed graph), every row   */
+    /* is walked by its row kernel, so a stale hint costs time, never correctness.                                              */
     int32_t *hub_report;
     const int32_t *report_hub_count;
     const int32_t *report_mega_count;
