@@ -7,15 +7,17 @@
 // row's LAST slice -- ticket counter -- combines them) -- and a unit is walked by all wavefronts of a workgroup, 64-neighbour chunks
 // dealt round robin, partials combined through LDS.
 //
-// Round 4: the units are served by the LEADING workgroups of the row kernel's own launch (`hub_blocks` of them, 256 threads = 4
+// Round 4: the units are served by the LEADING workgroups of a row kernel's own launch (`hub_blocks` of them, 256 threads = 4
 // wavefronts each; the row workgroups follow).  As launches of their own (rounds 1-3: 256 workgroups of 16 wavefronts after every
 // row kernel) the passes were a serial chain of ~15-40 us per hop that nothing overlapped -- 35 us of a 0.49 ms step at rank^-0.5,
-// 113 us of 0.52 ms at rank^-0.9 --, and on a second stream they only started in the row kernel's tail (DESIGN 3.5).  Inside the
-// launch they start FIRST (workgroups are dispatched in index order) and the row workgroups fill the chip around them.  The
-// stand-alone kernels remain for the shapes without a specialised row kernel and for A/B runs (SS_HUB_LAUNCHES=1).
+// 113 us of 0.52 ms at rank^-0.9 --, and on a second stream they only started in the row kernel's tail (DESIGN 3.4b).  Inside the
+// launch they start FIRST (workgroups are dispatched in index order) and the row workgroups fill the chip around them.
+// Which launch hosts what: the HLL first-hop launch both hop-1 tables' units, the MinHash table-hop launch both tables' units of
+// its hop (ss_fused_hop_stage) or its own sketch's (ss_propagate); the fused kernel hosts none -- it has no register to spare.
+// The stand-alone kernels remain for the shapes without a specialised row kernel and for A/B runs (SS_HUB_LAUNCHES=1).
 //
-// Tickets: a mega row has one counter per sketch side (descriptor words 3 / 4), because the fused launch serves first-hop MinHash
-// units and table-hop HLL units of the same rows at the same time.
+// Tickets: a mega row has one counter per sketch side (descriptor words 3 / 4), because MinHash units and HLL units of the same
+// rows are served by different workgroups of ONE launch, at the same time.
 #pragma once
 #include <cstdlib>
 
