@@ -300,9 +300,17 @@ __device__ __forceinline__ bool first_hop_minhash_fast(const int32_t *__restrict
         b8[q] = (uint32_t)b[q] + 8u;
     }
     bool seen_self = false;  // the row lists its own node explicitly (graphs that already carry self loops)
+    // (the ids of the NEXT batch are requested before the current one is walked -- unconditionally, from a word that always exists
+    // for the lanes past the row's end: a hub unit's wavefront walks 4 - 16 batches, each of which began with an exposed round trip)
+    const int32_t *always_valid = nb;  // (deg >= 1 whenever a batch exists beyond the self loop; nb[0] is never out of bounds then)
+    int t_first = first_batch * kWave + lane;
+    int cur = deg > 0 ? *(t_first < deg ? nb + t_first : always_valid) : 0;
     for (int base = first_batch * kWave; base < total; base += batch_stride * kWave) {
         const int t = base + lane;
-        const int64_t nid = t < deg ? (int64_t)nb[t] : self_row;
+        const int tn = t + batch_stride * kWave;
+        const int nxt = deg > 0 ? *(tn < deg ? nb + tn : always_valid) : 0;
+        const int64_t nid = t < deg ? (int64_t)cur : self_row;
+        cur = nxt;
         const uint64_t hv = hash_u64((uint64_t)(nid + 1));
         const uint32_t hv_lo = (uint32_t)hv, hv_hi = (uint32_t)(hv >> 32);
         int cnt = total - base < kWave ? total - base : kWave;
