@@ -761,12 +761,20 @@ struct RunEdges {
 
     // descriptors of the tiles [b0, b0 + n), n <= kRunCap -> LDS; returns the number of edges in them
     // (o0_sum: the thread's run offsets inside their tiles are added -- summed over the tiles of a group that is the bucket's start)
-    __device__ __forceinline__ uint32_t prepare(int b0, int n, unsigned long long *o0_sum = nullptr) const
+    // prepare = scan + tables.  Split for the finish launch, which announces its decision (ordinary bucket / dense bucket) between the
+    // two -- as soon as the edge count is known, ~2 us before the tables stand -- and registers a dense bucket's shares from the
+    // prefix the scan left in its registers (no second pass over the descriptors)
+    struct Scan {
+        uint32_t total, ex;            // edges of the listed runs; position of this thread's first run (descriptor threadIdx.x * kPer)
+        uint32_t len[kPer], addr[kPer];  // this thread's run lengths (0 past the end) and first records
+    };
+    __device__ __forceinline__ Scan scan(int b0, int n, unsigned long long *o0_sum = nullptr) const
     {
         const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
         // (every descriptor word is loaded UNCONDITIONALLY from a clamped index and only its use is predicated: loads under
-        // `if (i < n)` are awaited branch by branch -- kPer dependent round trips at the head of every bucket, 2 of its 5 us)
-        uint32_t len[kPer], addr[kPer], o0[kPer], o1[kPer], ts[kPer], run = 0;
+        // `if (i < n)` are awaited branch by branch)
+        Scan sc;
+        uint32_t o0[kPer], o1[kPer], ts[kPer], run = 0;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const int i = threadIdx.x * kPer + j;
@@ -779,10 +787,10 @@ struct RunEdges {
         for (int j = 0; j < kPer; ++j) {
             const int i = threadIdx.x * kPer + j;
             const bool in = i < n;
-            len[j] = in ? o1[j] - o0[j] : 0u;
-            addr[j] = in ? ts[j] + o0[j] : 0u;
+            sc.len[j] = in ? o1[j] - o0[j] : 0u;
+            sc.addr[j] = in ? ts[j] + o0[j] : 0u;
             if (o0_sum && in) *o0_sum += o0[j];
-            run += len[j];
+            run += sc.len[j];
         }
         uint32_t inc = run;
 #pragma unroll
@@ -798,16 +806,23 @@ struct RunEdges {
             if (w < wv) pre += lds->wave_tot[w];
             total += lds->wave_tot[w];
         }
-        uint32_t ex = pre + inc - run;
+        sc.total = total;
+        sc.ex = pre + inc - run;
+        return sc;
+    }
+    __device__ __forceinline__ void tables(int n, const Scan &sc) const
+    {
+        uint32_t ex = sc.ex;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const int i = threadIdx.x * kPer + j;
             if (i < n) {
                 lds->start[i] = (uint16_t)ex;
-                lds->delta[i] = addr[j] - ex;
+                lds->delta[i] = sc.addr[j] - ex;
             }
-            ex += len[j];
+            ex += sc.len[j];
         }
+        const uint32_t total = sc.total;
         if (threadIdx.x < 4) lds->start[n + threadIdx.x] = threadIdx.x == 0 ? (uint16_t)total : (uint16_t)0xFFFF;
         __syncthreads();
         // (a bucket above kDenseMin edges is not walked by its workgroup -- it goes to the dense steps, whose shares are walkable:
@@ -823,7 +838,12 @@ struct RunEdges {
             lds->first_run[q] = (uint16_t)a;
         }
         __syncthreads();
-        return total;
+    }
+    __device__ __forceinline__ uint32_t prepare(int b0, int n, unsigned long long *o0_sum = nullptr) const
+    {
+        const Scan sc = scan(b0, n, o0_sum);
+        tables(n, sc);
+        return sc.total;
     }
     // the run of position p: the first run of p's 64-position block from the table (uniform over a wavefront), plus one for each of the
     // next three run starts at or before p -- three independent reads, no loop: the positions' chains interleave (twelve while-loops of
@@ -996,6 +1016,43 @@ struct DenseRunArgs {
             carry += tot;
         }
         if (helpers) {  // the helpers of THIS launch read the descriptor, the share bounds and the zeroed counters: publish (G16 producer form)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // the same registration from what RunEdges::prepare left in the registers of the bucket's workgroup (thread i: the position `ex`
+    // of the run of tile t_lo + i * KPER and the lengths of its KPER runs): no second pass over the descriptors, no second scan
+    // (rank^-0.5 endpoints at collab size: the dense buckets are registered 7.5 us into the launch instead of 12.5)
+    template <int KPER>
+    __device__ __forceinline__ void register_from_prefix(FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int nb, uint32_t ex,
+                                                         const uint32_t (&len)[KPER]) const
+    {
+        const int shares = (int)((seg_n + kDensePart - 1) / kDensePart);
+        if (threadIdx.x == 0) {
+            const int d = atomicAdd(&count[0], 1);
+            const int first = atomicAdd(&count[1], shares);
+            list[d] = DenseRunBucket{(int32_t)blockIdx.x, first, shares, t_hi, seg_n, seg_lo};
+            share_lo[first] = (uint32_t)t_lo;
+            lds.excl[0] = (uint32_t)d;
+            lds.excl[1] = (uint32_t)first;
+        }
+        __syncthreads();
+        const int d = (int)lds.excl[0], first = (int)lds.excl[1];
+        uint32_t *mine = node_cnt + (size_t)d * 1024;
+        for (int i = threadIdx.x; i < nb; i += (int)blockDim.x) mine[i] = 0;
+#pragma unroll
+        for (int j = 0; j < KPER; ++j) {
+            const int t = t_lo + (int)threadIdx.x * KPER + j;
+            const uint32_t after = ex + len[j];  // (len is 0 for the descriptors past t_hi)
+            const uint32_t s_hi = after / (uint32_t)kDensePart, s_lo = ex / (uint32_t)kDensePart;
+            if (s_hi != s_lo && s_hi < (uint32_t)shares && t < t_hi) share_lo[first + s_hi] = (uint32_t)(t + 1);  // (a run is at most a tile: one crossing)
+            ex = after;
+        }
+        if (helpers) {  // publish (G16 producer form), as register_bucket
             __syncthreads();
             if (threadIdx.x == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1232,8 +1289,20 @@ __global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel pa
     unsigned long long base = 0, mx = 0;
     uint32_t n = 0;
     const bool resident = edges.resident();  // (workgroup-uniform) one descriptor per thread: loaded once, for the sums and the walks
+    typename RunEdges<PACKED, kRunThreads>::Scan sc = {};
+    bool announced = false;
+    dense.t_lo = c.t_lo;
+    dense.t_hi = c.t_hi;
     if (resident) {
-        const uint32_t total = edges.prepare(c.t_lo, c.t_hi - c.t_lo, &base);
+        // the decision (ordinary / dense) is announced as soon as the edge count is known, before the run tables are built: the
+        // helpers wait for every bucket's
+        sc = edges.scan(c.t_lo, c.t_hi - c.t_lo, &base);
+        announced = true;
+        if (sc.total <= (uint32_t)kDenseMin) {  // (workgroup-uniform)
+            dense.arrive();
+            edges.tables(c.t_hi - c.t_lo, sc);
+        }
+        const uint32_t total = sc.total;
         n = threadIdx.x == 0 ? total : 0u;
     } else {
         for (int t = c.t_lo + threadIdx.x; t < c.t_hi; t += kRunThreads) {
@@ -1279,11 +1348,12 @@ __global__ __launch_bounds__(kRunThreads) void finish_runs_kernel(ParentLevel pa
     SS_TICK(0);
     const int nb = 1 << node_shift;  // <= 1024 nodes
     if (n > (uint32_t)kDenseMin) {  // (workgroup-uniform) does not fit the image: split over several workgroups by the dense steps
-        dense.register_bucket(lds, base, n, nb);
+        if (announced) dense.register_from_prefix(lds, base, n, nb, sc.ex, sc.len);
+        else dense.register_bucket(lds, base, n, nb);
         SS_MARK(14);
         return;
     }
-    dense.arrive();
+    if (!announced) dense.arrive();
     SS_MARK(15);
     uint32_t *cnt = lds.cnt;
     for (int i = threadIdx.x; i < nb; i += kRunThreads) cnt[i] = 0;
