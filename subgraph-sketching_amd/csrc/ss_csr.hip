@@ -61,8 +61,9 @@ constexpr int kRunCap = 1024;          // run descriptors the finish step keeps 
 constexpr int kDenseMin = kFinishCap;  // a fine bucket with more edges than this is split ...
 constexpr int kDensePart = 8192;       // ... into shares of about this many edges
 constexpr int kDenseGrid = 1024;       // workgroups of the two dense launches (each loops over the shares)
-// dense_count words: [0] dense buckets, [1] shares, [3] helpers done counting, [kArriveBase + 16 k] (k < kArriveWords, one cache
-// line each) fine buckets whose workgroup has decided -- 64 sharded words: one word takes ~90 atomics per microsecond
+// dense_count words: [0] dense buckets, [1] shares, [2] / [3] / [4] the helpers' count-claim, counted and place-claim counters,
+// [kArriveBase + 16 k] (k < kArriveWords, one cache line each) fine buckets whose workgroup has decided -- 64 sharded words: one word
+// takes ~90 atomics per microsecond
 constexpr int kArriveBase = 16, kArriveWords = 64, kDenseSyncInts = kArriveBase + 16 * kArriveWords;
 
 // average edges of a fine bucket the plans aim for: 3/4 of the image (a bucket above it goes to the dense steps, at some cost;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // outputs of the finish launch of this build are cleared here
         if (hub_count) *hub_count = 0;
         if (mega_count) mega_count[0] = mega_count[1] = 0;
-        dense_count[0] = dense_count[1] = dense_count[2] = dense_count[3] = 0;
+        for (int i = 0; i < 8; ++i) dense_count[i] = 0;  // [0] dense buckets, [1] shares, [2] / [3] / [4] the helpers' claim and done counters
     }
     if (blockIdx.x == 0 && threadIdx.x < kArriveWords) dense_count[kArriveBase + 16 * threadIdx.x] = 0;
     if (threadIdx.x < kMaxKeys) tile_hist[threadIdx.x] = 0;
@@ -969,6 +970,7 @@ struct DenseRunArgs {
     uint32_t *node_cnt;       // [dense bucket][1024]
     uint32_t *share_off;      // [share][1024]
     uint32_t *share_lo;       // [share] first tile of each share
+    int32_t *claim;           // [share] (helpers) 0 until a helper has taken the share for placing; zeroed by the registration
     const uint32_t *row0, *row1;  // descriptor rows of the registering bucket (set per workgroup)
     int t_lo, t_hi;
     int helpers;              // helper workgroups appended to the finish launch (0: the dense steps are launches of their own)
@@ -989,6 +991,7 @@ struct DenseRunArgs {
         const int d = (int)lds.excl[0], first = (int)lds.excl[1];
         uint32_t *mine = node_cnt + (size_t)d * 1024;
         for (int i = threadIdx.x; i < nb; i += (int)blockDim.x) mine[i] = 0;
+        for (int i = threadIdx.x; i < shares; i += (int)blockDim.x) claim[first + i] = 0;
         const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
         uint32_t carry = 0;
         for (int t0 = t_lo; t0 < t_hi; t0 += (int)blockDim.x) {
@@ -1044,6 +1047,7 @@ struct DenseRunArgs {
         const int d = (int)lds.excl[0], first = (int)lds.excl[1];
         uint32_t *mine = node_cnt + (size_t)d * 1024;
         for (int i = threadIdx.x; i < nb; i += (int)blockDim.x) mine[i] = 0;
+        for (int i = threadIdx.x; i < shares; i += (int)blockDim.x) claim[first + i] = 0;
 #pragma unroll
         for (int j = 0; j < KPER; ++j) {
             const int t = t_lo + (int)threadIdx.x * KPER + j;
@@ -1075,7 +1079,7 @@ struct DenseRunLds {
     uint32_t cnt[1024], excl[1024 + 1];
     uint32_t wave_tot[kDenseThreads / kWave];
     RunLds runs;
-    int desc;
+    int desc, claim;
 };
 static_assert(sizeof(DenseRunLds) <= sizeof(int32_t) * kFinishCap, "the helpers' LDS aliases the finish step's col image");
 
@@ -1132,28 +1136,33 @@ __device__ __forceinline__ void dense_count_run_shares(DenseRunLds &lds, int fir
 }
 
 // row starts from the summed counters (the first share of a bucket also publishes rowptr and the hub lists), then every edge of the
-// share goes to start + share offset + LDS cursor
+// share goes to start + share offset + LDS cursor.  (The counters and share offsets may have been written by other workgroups of
+// THIS launch -- helpers: they are read past the L1 with agent-scope loads.)
+template <bool PACKED, int THREADS>
+__device__ __forceinline__ void dense_place_run_share(DenseRunLds &lds, int item, int n_dense, const DenseRunWork &w, const RowOutputs &o)
+{
+    const int nb = 1 << w.node_shift;
+    DenseRunBucket b;
+    const RunEdges<PACKED, THREADS> edges = locate_run_share<PACKED, THREADS>(lds, item, n_dense, w, b);
+    const uint32_t *total = w.node_cnt + (size_t)lds.desc * 1024;
+    for (int i = threadIdx.x; i < nb; i += THREADS)
+        lds.cnt[i] = __hip_atomic_load(const_cast<uint32_t *>(total) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    scan_bucket_nodes(lds.cnt, lds.excl, lds.wave_tot, nb, (int64_t)b.bucket << w.node_shift, w.N, b.base, b.n, item == b.first_share, o);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += THREADS)
+        lds.cnt[i] = lds.excl[i] + __hip_atomic_load(w.share_off + (size_t)item * 1024 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned long long cbase = b.base;
+    int32_t *col = w.col;
+    edges.for_each([&](int x, int y) { col[cbase + atomicAdd(&lds.cnt[y], 1u)] = x; });
+}
+
 template <bool PACKED, int THREADS>
 __device__ __forceinline__ void dense_place_run_shares(DenseRunLds &lds, int first, int stride, int n_dense, int n_shares, const DenseRunWork &w,
                                                        const RowOutputs &o)
 {
-    const int nb = 1 << w.node_shift;
-    for (int item = first; item < n_shares; item += stride) {
-        DenseRunBucket b;
-        const RunEdges<PACKED, THREADS> edges = locate_run_share<PACKED, THREADS>(lds, item, n_dense, w, b);
-        const uint32_t *total = w.node_cnt + (size_t)lds.desc * 1024;
-        // (the totals were formed by other workgroups' agent-scope atomics, possibly in this launch: read them past the L1)
-        for (int i = threadIdx.x; i < nb; i += THREADS)
-            lds.cnt[i] = __hip_atomic_load(const_cast<uint32_t *>(total) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        scan_bucket_nodes(lds.cnt, lds.excl, lds.wave_tot, nb, (int64_t)b.bucket << w.node_shift, w.N, b.base, b.n, item == b.first_share, o);
-        __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += THREADS) lds.cnt[i] = lds.excl[i] + w.share_off[(size_t)item * 1024 + i];
-        __syncthreads();
-        const unsigned long long cbase = b.base;
-        int32_t *col = w.col;
-        edges.for_each([&](int x, int y) { col[cbase + atomicAdd(&lds.cnt[y], 1u)] = x; });
-    }
+    for (int item = first; item < n_shares; item += stride) dense_place_run_share<PACKED, THREADS>(lds, item, n_dense, w, o);
 }
 
 template <bool PACKED>
@@ -1173,13 +1182,22 @@ __global__ __launch_bounds__(kDenseThreads) void dense_place_runs_kernel(DenseRu
     dense_place_run_shares<PACKED, kDenseThreads>(lds, blockIdx.x, gridDim.x, dense_count[0], dense_count[1], w, o);
 }
 
-// helper workgroups of the finish launch (blockIdx >= the number of fine buckets; see dense_helper above for the protocol and why
-// the bound on their number excludes a deadlock): wait until every bucket workgroup has decided, leave if nothing was registered,
-// otherwise count, meet the other helpers at a counter barrier, place
-// the helpers' records between their two steps: the part of the finish step's image behind DenseRunLds (a share is at most
-// kDensePart edges + one run: 12 288 records)
+// ---- helper workgroups of the finish launch (blockIdx >= the number of fine buckets; one-level plans) -------------------------
+// They wait until every bucket workgroup of the launch has decided (those were dispatched before any helper and never wait), leave
+// if nothing was registered, and otherwise count and place the shares of the dense buckets.  Shares are CLAIMED (an atomic counter),
+// not assigned: a helper takes the next share, counts it, takes another; when none is left it waits until every share HAS BEEN counted
+// -- each of which is in the hands of a workgroup that is running, not waiting -- and then places the same way.  No step needs a
+// helper that is not resident yet, so nothing can deadlock whatever else shares the device.  (Until round 4 share s belonged to
+// helper s and the helpers met at a counter barrier that needed ALL of them resident: safe for one or two processes per device by the
+// quarter rule of helper_budget -- and a deadlock, ended by the spin limit's trap, once in a dozen runs of eight processes building
+// skewed graphs on one GPU, test_sharded_build_two_ranks_one_gpu[8].)  A helper keeps the records of the LAST share it counted in
+// LDS behind its tables and places that one from there -- no second descriptor table, no second gather; with at most one share per
+// helper, the usual case, that is every share (placing step 13.4 -> 7.5 us at rank^-0.5, collab size).
+// Hand-offs follow Guideline 16 (stores -> barrier -> lane-0 agent release -> s_waitcnt vmcnt(0) -> relaxed atomic; poll -> agent
+// acquire -> barrier); words written by other workgroups of the launch are read with agent-scope loads.
 constexpr int kHelperStashWord = (int)((sizeof(DenseRunLds) + 255) / 256 * 256 / 4);
-constexpr int kHelperStashCap = kFinishCap - kHelperStashWord;
+constexpr int kHelperStashCap = kFinishCap - kHelperStashWord;  // (a share is at most kDensePart edges + one run: 12 288 records)
+constexpr int kCountClaim = 2, kCountDone = 3, kPlaceClaim = 4;  // words of dense.count (zeroed by the tile sort of the build)
 
 template <bool PACKED>
 __device__ __forceinline__ void dense_run_helper(DenseRunLds &lds, uint32_t *stash, int helper, int n_buckets, const DenseRunWork &w,
@@ -1190,40 +1208,27 @@ __device__ __forceinline__ void dense_run_helper(DenseRunLds &lds, uint32_t *sta
     const int n_dense = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int n_shares = __hip_atomic_load(&dense.count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n_shares == 0) return;  // every unskewed graph
-    auto counted = [&]() {  // every helper: this workgroup's counters are out -> wait for everybody's
-        __syncthreads();
-        SS_MARK(11);
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(&dense.count[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        wait_for_count(&dense.count[3], 1, 0, dense.helpers);
-        SS_MARK(12);
-    };
-    if (!PACKED || n_shares > dense.helpers) {  // (uniform over the launch) some helper has several shares: two sweeps over each
-        dense_count_run_shares<PACKED, kRunThreads>(lds, helper, dense.helpers, n_dense, n_shares, w);
-        counted();
-        dense_place_run_shares<PACKED, kRunThreads>(lds, helper, dense.helpers, n_dense, n_shares, w, o);
-        SS_MARK(13);
-        return;
-    }
-    // At most ONE share per helper (every graph but the most skewed): the share's records stay in LDS between the two steps, as in
-    // an ordinary bucket's workgroup -- no second descriptor table, no second gather (rank^-0.5 endpoints at collab size: the
-    // placing step 13.4 -> 7.5 us, the finish launch 42 -> 35)
     const int nb = 1 << w.node_shift;
     constexpr int kPerThread = 1024 / kRunThreads;  // node counters per thread
-    const bool mine = helper < n_shares;  // workgroup-uniform
+    auto take = [&](int32_t *word) {  // (all threads) the next ticket of an agent-scope counter
+        __syncthreads();
+        if (threadIdx.x == 0) lds.claim = __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        return lds.claim;
+    };
+    // ---- count
+    int mine = -1, d = 0;  // the share whose records (and run tables) this workgroup still holds
     DenseRunBucket b = {};
     RunEdges<PACKED, kRunThreads> edges = {};
-    uint32_t total = 0, off[kPerThread];
+    uint32_t total = 0, off[kPerThread] = {};
     bool stashed = false;
-    int d = 0;
-    if (mine) {
-        edges = locate_run_share<PACKED, kRunThreads>(lds, helper, n_dense, w, b);
+    for (;;) {
+        const int s = take(&dense.count[kCountClaim]);
+        if (s >= n_shares) break;  // workgroup-uniform
+        edges = locate_run_share<PACKED, kRunThreads>(lds, s, n_dense, w, b);
         d = lds.desc;
         total = edges.resident() ? lds.runs.start[edges.t_hi - edges.t_lo] : 0u;
-        stashed = edges.resident() && total <= (uint32_t)kHelperStashCap;
+        stashed = PACKED && edges.resident() && total <= (uint32_t)kHelperStashCap;
         for (int i = threadIdx.x; i < nb; i += kRunThreads) lds.cnt[i] = 0;
         __syncthreads();
         if (stashed) edges.for_each_stash(stash, [&](int, int y) { atomicAdd(&lds.cnt[y], 1u); });
@@ -1235,28 +1240,51 @@ __device__ __forceinline__ void dense_run_helper(DenseRunLds &lds, uint32_t *sta
             const int i = threadIdx.x + k * kRunThreads;
             const uint32_t c = i < nb ? lds.cnt[i] : 0u;
             off[k] = c ? atomicAdd(&sum[i], c) : 0u;  // (where this share's edges of node i start inside the node's row)
+            if (i < nb) w.share_off[(size_t)s * 1024 + i] = off[k];  // (for whoever places the share, should it not be this workgroup)
+        }
+        mine = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {  // this share is counted
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&dense.count[kCountDone], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    counted();
-    if (mine) {
-        const uint32_t *sum = w.node_cnt + (size_t)d * 1024;
-        // (the totals were formed by other workgroups' agent-scope atomics in this launch: read them past the L1)
-        for (int i = threadIdx.x; i < nb; i += kRunThreads)
-            lds.cnt[i] = __hip_atomic_load(const_cast<uint32_t *>(sum) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SS_MARK(11);
+    wait_for_count(&dense.count[kCountDone], 1, 0, n_shares);
+    SS_MARK(12);
+    // ---- place: first the share whose records are still here, then whatever nobody has taken
+    if (mine >= 0) {
         __syncthreads();
-        scan_bucket_nodes(lds.cnt, lds.excl, lds.wave_tot, nb, (int64_t)b.bucket << w.node_shift, w.N, b.base, b.n, helper == b.first_share, o);
+        if (threadIdx.x == 0) lds.claim = __hip_atomic_exchange(&dense.claim[mine], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        if (lds.claim == 0) {  // workgroup-uniform
+            const uint32_t *sum = w.node_cnt + (size_t)d * 1024;
+            for (int i = threadIdx.x; i < nb; i += kRunThreads)
+                lds.cnt[i] = __hip_atomic_load(const_cast<uint32_t *>(sum) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            scan_bucket_nodes(lds.cnt, lds.excl, lds.wave_tot, nb, (int64_t)b.bucket << w.node_shift, w.N, b.base, b.n, mine == b.first_share, o);
+            __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kPerThread; ++k) {
-            const int i = threadIdx.x + k * kRunThreads;
-            if (i < nb) lds.cnt[i] = lds.excl[i] + off[k];
+            for (int k = 0; k < kPerThread; ++k) {
+                const int i = threadIdx.x + k * kRunThreads;
+                if (i < nb) lds.cnt[i] = lds.excl[i] + off[k];
+            }
+            __syncthreads();
+            const unsigned long long cbase = b.base;
+            int32_t *col = w.col;
+            auto place = [&](int x, int y) { col[cbase + atomicAdd(&lds.cnt[y], 1u)] = x; };
+            if (stashed) edges.replay(stash, total, place);
+            else edges.for_each(place);
         }
+    }
+    for (;;) {
+        const int s = take(&dense.count[kPlaceClaim]);
+        if (s >= n_shares) break;
         __syncthreads();
-        const unsigned long long cbase = b.base;
-        int32_t *col = w.col;
-        auto place = [&](int x, int y) { col[cbase + atomicAdd(&lds.cnt[y], 1u)] = x; };
-        if (stashed) edges.replay(stash, total, place);
-        else edges.for_each(place);
+        if (threadIdx.x == 0) lds.claim = __hip_atomic_exchange(&dense.claim[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (lds.claim == 0) dense_place_run_share<PACKED, kRunThreads>(lds, s, n_dense, w, o);  // (workgroup-uniform)
     }
     SS_MARK(13);
 }
@@ -1390,6 +1418,7 @@ struct Workspace {
     int32_t *dense_count;           // [kDenseSyncInts]
     DenseRunBucket *dense_list;
     uint32_t *dense_node_cnt, *dense_share_off, *dense_share_lo;
+    int32_t *dense_claim;           // [shares] (helpers: who places a share)
     size_t bytes;
 };
 
@@ -1422,6 +1451,7 @@ inline Workspace carve(const LevelPlan &p, int64_t E, void *base)
     w.dense_node_cnt = reinterpret_cast<uint32_t *>(take((size_t)db * 1024 * 4));
     w.dense_share_off = reinterpret_cast<uint32_t *>(take((size_t)ds * 1024 * 4));
     w.dense_share_lo = reinterpret_cast<uint32_t *>(take((size_t)(ds + 1) * 4));
+    w.dense_claim = reinterpret_cast<int32_t *>(take((size_t)(ds + 1) * 4));
     w.bytes = off;
     return w;
 }
@@ -1544,10 +1574,11 @@ int helper_budget(Kernel kernel)
     return (int)(h > 0 ? h : 0);
 }
 
-// fewer CUs than the device has, for this process or this stream?  The helpers' bound (a quarter of the workgroups the WHOLE device
-// can hold) means nothing then, and a helper that waits for helpers that cannot become resident waits for ever: such launches take
-// the stand-alone dense steps.  The global masks are environment variables of the runtime; a stream's own mask
-// (hipExtStreamCreateWithCUMask) is asked of the stream -- one entry remembered per thread, builds mostly stay on one stream.
+// fewer CUs than the device has, for this process or this stream?  The helpers' number (a quarter of the workgroups the WHOLE device
+// can hold) is the wrong size then -- they would crowd the bucket workgroups they wait for off the few CUs there are: such launches
+// take the stand-alone dense steps (since the helpers claim their shares they can no longer deadlock there, only
+// crawl).  The global masks are environment variables of the runtime; a stream's own mask (hipExtStreamCreateWithCUMask) is asked
+// of the stream -- one entry remembered per thread, builds mostly stay on one stream.
 inline bool cu_masked(hipStream_t stream, int dev)
 {
     static const bool global_mask = getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK");
@@ -1694,7 +1725,7 @@ static int csr_build_launch(const ss::LevelPlan &lp, const int64_t *src, const i
     // launch; larger builds by two launches of their own (~9 us of a build of hundreds when they find nothing to do)
     int helpers = lp.levels == 1 ? run_helpers(packed, stream) : 0;
     if ((int64_t)helpers > share_cap) helpers = (int)share_cap;
-    const DenseRunArgs dense = {w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, w.dense_share_lo, nullptr, nullptr, 0, 0, helpers};
+    const DenseRunArgs dense = {w.dense_count, w.dense_list, w.dense_node_cnt, w.dense_share_off, w.dense_share_lo, w.dense_claim, nullptr, nullptr, 0, 0, helpers};
     const DenseRunWork work = {par, in, lp.node_shift, lp.src_bits, N, w.dense_list, w.dense_share_lo, w.dense_node_cnt, w.dense_share_off, col};
     if (packed) {
         hipLaunchKernelGGL(finish_runs_kernel<true>, dim3((unsigned)(fine + helpers)), dim3(kRunThreads), 0, stream, par, in, w.tile_max, tiles0,
