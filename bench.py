@@ -499,9 +499,9 @@ def main():
         if launched:
             gather.drain()
         torch.cuda.synchronize(dev)
-        if launched:
+        if launched:  # (one process: the synchronisation above is the whole fence)
             dist.barrier()
-        torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev)
 
     # steady state first: clocks, caches, allocator pools and the hub hint of this shape (disclosed as `settle_seconds`; not timed)
     settle_steps = 0
