@@ -723,7 +723,7 @@ __device__ __forceinline__ void wait_for_count(int32_t *first, int words, int st
             for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
             if (v >= target) break;  // wave-uniform
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1L << 26)) __builtin_trap();  // (minutes: a launch error instead of a hang if the protocol is ever broken)
+            if (++spins > (1L << 28)) __builtin_trap();  // (tens of seconds: a launch error instead of a hang if the protocol is ever broken)
         }
         if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -1189,8 +1189,8 @@ __global__ __launch_bounds__(kDenseThreads) void dense_place_runs_kernel(DenseRu
 // -- each of which is in the hands of a workgroup that is running, not waiting -- and then places the same way.  No step needs a
 // helper that is not resident yet, so nothing can deadlock whatever else shares the device.  (Until round 4 share s belonged to
 // helper s and the helpers met at a counter barrier that needed ALL of them resident: safe for one or two processes per device by the
-// quarter rule of helper_budget -- and a deadlock, ended by the spin limit's trap, once in a dozen runs of eight processes building
-// skewed graphs on one GPU, test_sharded_build_two_ranks_one_gpu[8].)  A helper keeps the records of the LAST share it counted in
+// quarter rule of helper_budget -- and a possible deadlock, ended by the spin limit's trap, for eight processes building skewed
+// graphs on one GPU as test_sharded_build_two_ranks_one_gpu[8] does.)  A helper keeps the records of the LAST share it counted in
 // LDS behind its tables and places that one from there -- no second descriptor table, no second gather; with at most one share per
 // helper, the usual case, that is every share (placing step 13.4 -> 7.5 us at rank^-0.5, collab size).
 // Hand-offs follow Guideline 16 (stores -> barrier -> lane-0 agent release -> s_waitcnt vmcnt(0) -> relaxed atomic; poll -> agent
