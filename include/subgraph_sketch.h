@@ -161,7 +161,7 @@ int ss_propagate(const ss_csr_graph *graph, const uint32_t *mh_in, uint32_t *mh_
 
 /* The MinHash half of ss_propagate for a LIST of destination rows: mh_out[r] = min over the in-neighbours of r (and r itself,
  * as above) for every r in rows[0 .. n_rows) -- ids may repeat, negative ids count from the end (torch indexing), ids outside
- * [-N, N) are ignored -- plus every hub row of the graph (the cooperative hub pass always serves all of them); all other rows
+ * [-N, N) are ignored -- plus every hub row of the graph (the hub units always cover all of them); all other rows
  * of mh_out are left untouched.  For the caller whose next step reads only a few rows of the hop's table: ELPH's training
  * step (models/elph.py:209-212 followed by runners/train.py:204) propagates over the whole graph and then queries two rows
  * per link of ONE batch; the host mirror defers the last minhash_prop (hashing.py:28-35) and computes the batch's rows

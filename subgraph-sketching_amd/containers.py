@@ -202,7 +202,7 @@ class LazyMinhash(torch.Tensor):
         if self._pending is not None and self._partial is not None:
             # ONE row-list launch per table (ELPH's training step: one forward, one batch).  A second reader of the same table
             # -- the reference's inference loop: one forward, many get_subgraph_features batches -- completes it instead: every
-            # partial launch also pays a hub pass over ALL hub rows, and the pending closure pins the previous hop's table
+            # partial launch also serves ALL hub rows (its hub units), and the pending closure pins the previous hop's table
             if self._partial_rows == 0 and rows.numel() <= self._packed.size(0):
                 self._partial_rows = rows.numel()
                 self._partial(rows.reshape(-1))

@@ -28,7 +28,7 @@ class CsrGraph(object):
         self.rowptr, self.col, self.num_nodes, self.n_self_dev, self.err = rowptr, col, num_nodes, n_self_dev, err
         self.hub_rows, self.hub_count, self.hub_threshold = hub_rows, hub_count, hub_threshold
         self.mega_rows, self.mega_count, self.mega_scratch = mega if mega is not None else (None, None, None)
-        self.has_hub_rows = True  # unknown (no host read of the device counters): keep the hub passes
+        self.has_hub_rows = True  # unknown (no host read of the device counters): keep the hub units
         self.pending_minhash = None  # (weakref to a LazyMinhash, perms, P, p): a deferred hop-1 MinHash table on this graph
         self.pending_lazies = []     # weakrefs to every LazyMinhash whose deferred launch refers to this graph
         self.num_edges = None
@@ -152,7 +152,7 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None, err
     csr.fingerprint = fp  # a later build_csr(..., reuse=csr) compares contents with these sums
     if check:
         # the one synchronising read of strict mode brings the hub / mega row counts along: a graph without such rows
-        # (every unskewed graph) then skips both hub-pass launches of every hop (4 us each)
+        # (every unskewed graph) then serves no hub units (leading workgroups that would find nothing to do)
         host = flags32.cpu()
         if int(host[3]):
             raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
@@ -184,7 +184,7 @@ class _CsrCache(object):
         # differ, decided on the device (knobs.REUSE_CSR_BY_CONTENT; strict builds read their flags back and always rebuild)
         reuse = self._csr if (knobs.REUSE_CSR_BY_CONTENT and self._key == key) else None
         csr = build_csr(edge_index, num_nodes, device, check=check, err_flag=err_flag, reuse=reuse, fingerprint=knobs.REUSE_CSR_BY_CONTENT)
-        if self._hub_hint is not None and not check:  # (ElphHashes._hub_hint: no hub-pass launches for shapes that listed no hub rows)
+        if self._hub_hint is not None and not check:  # (ElphHashes._hub_hint: no hub units for shapes that listed no hub rows)
             hint = self._hub_hint(device, num_nodes, edge_index)
             if hint is not None:
                 csr.hub_report, csr.has_hub_rows = hint[0], not hint[1]

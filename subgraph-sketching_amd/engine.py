@@ -72,7 +72,7 @@ class ElphHashes(object):
         # link sets of >= knobs.GROUP_LINKS_MIN pairs: 'auto' = grouped by their first node unless the list already has its runs (one
         # host read per such call), True = always grouped, False = walked as listed (no host read)
         self.group_links = 'auto'
-        # skip the hub-pass launches of build_hash_tables for shapes whose earlier builds listed no hub rows (see _hub_hint)
+        # skip the hub units of build_hash_tables for shapes whose earlier builds listed no hub rows (see _hub_hint)
         self.hub_hints = os.environ.get('SS_HUB_HINTS', '1') != '0'
         self._hub_words, self._hub_arena = {}, None
 
@@ -205,10 +205,11 @@ class ElphHashes(object):
     def _hub_hint(self, device, num_nodes, edge_index):
         """-> (pinned host word a build of this shape reports its hub + mega row count into, whether an EARLIER build of
         the shape reported none).  The word is read without synchronising -- it holds whatever the most recent COMPLETED build of
-        the shape left (-1: none yet) -- and is only a hint: with it, an unskewed graph is built without the two hub-pass launches
-        per hop that find nothing to do (9 us of a 0.455 ms step at ogbl-collab size); if the hint is stale (another graph of the
+        the shape left (-1: none yet) -- and is only a hint: with it, an unskewed graph is built without hub lists (no leading hub
+        workgroups in its launches; rounds 1-3: without the two hub-pass launches per hop that found nothing to do, 9 us of a 0.455 ms
+        step at ogbl-collab size); if the hint is stale (another graph of the
         same shape that does have hub rows) those rows are walked by single wavefronts once -- slow, never wrong -- and the next
-        build of the shape has its hub passes back.  `eh.hub_hints = False` keeps the passes unconditionally."""
+        build of the shape has its hub units back.  `eh.hub_hints = False` keeps them unconditionally."""
         key = (str(device), int(num_nodes), tuple(edge_index.shape), knobs.HUB_THRESHOLD)
         word = self._hub_words.get(key)
         if word is None:
@@ -247,7 +248,7 @@ class ElphHashes(object):
         report, no_hubs = (None, False) if (check or not self.hub_hints) else self._hub_hint(device, num_nodes, edge_index)
         csr = build_csr(edge_index, num_nodes, device, check=check, err_flag=err_flag)
         csr.hub_report = report  # (the first-hop kernels of this build leave its hub + mega row count there)
-        if no_hubs:  # an earlier build of this shape listed no hub / mega rows: no hub passes (the row kernels walk every row)
+        if no_hubs:  # an earlier build of this shape listed no hub / mega rows: no hub units (the row kernels walk every row)
             csr.has_hub_rows = False
         csr.use_inferred_self_loops = True
         rows = None if shard is None else shard.rows
@@ -294,7 +295,7 @@ class ElphHashes(object):
                 _propagate(csr, mh[k - 2], hll[k - 2], device, cards_out=cards[:, k - 1], cards_stride=h, params=params,
                            mh_out=mh[k - 1], hll_out=hll[k - 1])
         elif shard is None:
-            # (inside the library each of these calls is one launch per sketch + one hub pass: measured faster than
+            # (inside the library each of these calls is one launch per sketch, each hosting its hub units: measured faster than
             # two-sketch kernels -- first hop 37 + 134 us vs 184, table hop 111 + 192 us vs 326 on the bench graph)
             for k in range(1, h + 1):
                 if k == 1 and fused:
