@@ -34,9 +34,13 @@ int ss_profile_enable(uint32_t tag_mask);   /* bit t enables family t; 0 disable
 /* Library calls since the last reset that were given hub lists and served hub units -- hosted by their row launches (which leave no
  * SS_PROF_HUB span) or as launches of their own; reset != 0 returns the count and clears it.  For the tests of the hub hints. */
 int64_t ss_debug_hub_calls(int32_t reset);
-/* Helper workgroups a one-level ss_csr_build launched on `stream` would append to its finish launch (0: the stand-alone dense
- * launches -- SS_CSR_DENSE=launch, a CU mask on the process or on the stream).  For the test of the CU-mask rule. */
+/* Dedicated helper workgroups an ss_csr_build appends to its finish launch (SS_CSR_HELPERS caps it; `stream` is ignored: since
+ * round 5 nothing waits for a helper, so a CU mask on the stream no longer changes the schedule). */
 int ss_debug_csr_helpers(void *stream);
+/* Cross-workgroup waits of any CSR build of this process that gave up after their ~2 s bound (ss_csr.hip "who may wait for whom":
+ * only running workgroups are ever waited for, so this stays 0; the tests of the multi-process and CU-masked builds assert it).
+ * -1: the counter could not be read. */
+int ss_debug_csr_protocol_faults(void);
 int ss_profile_read(int32_t tag, float *mean_ms_out, int32_t *launches_out);
 /* Time only every `every`-th launch of an enabled family (the first after ss_profile_enable, then each `every`-th): a timed launch costs
  * its step about 5 us (the completion signal the events are filled from), which is 1 % of the step bench.py times.  Default 1. */

@@ -33,7 +33,7 @@ class CsrGraphStruct(ctypes.Structure):
                 ('mirror_cards', c_void_p * 7), ('hub_report', c_void_p), ('report_hub_count', c_void_p), ('report_mega_count', c_void_p)]
 
 
-ABI_VERSION = 127  # ss_version() of the library this module's struct mirrors and signatures describe
+ABI_VERSION = 128  # ss_version() of the library this module's struct mirrors and signatures describe
 PROF_MINHASH_HOP, PROF_HLL_HOP, PROF_FIRST_HOP_MH, PROF_FIRST_HOP_HLL, PROF_PAIRS, PROF_CSR, PROF_HUB, PROF_FUSED, PROF_MINHASH_ROWS = range(9)  # SS_PROF_* tags
 MEGA_DESC_WORDS = 8  # SS_MEGA_DESC_WORDS
 MEGA_SLICE, MEGA_SLOT_BYTES, CSR_FINGERPRINT_BYTES, MAX_MIRRORS = 1024, 1280, 8448, 7  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
@@ -89,6 +89,7 @@ SIGNATURES = {
     'ss_profile_sample': (c_int32, [c_int32]),
     'ss_debug_hub_calls': (c_int64, [c_int32]),
     'ss_debug_csr_helpers': (c_int32, [c_void_p]),
+    'ss_debug_csr_protocol_faults': (c_int32, []),
     'ss_profile_read': (c_int32, [c_int32, POINTER(c_float), POINTER(c_int32)]),
     'ss_time_propagate': (c_int32, [POINTER(CsrGraphStruct), c_void_p, c_void_p, c_int32, c_void_p,
                                     c_void_p, c_int32, c_void_p, c_int64, POINTER(HllParams), c_void_p, c_int32,

@@ -36,7 +36,9 @@ inline int hub_lead_blocks(bool hubs)
     if (hubs) note_hub_call();
     static const bool launches = getenv("SS_HUB_LAUNCHES") && atoi(getenv("SS_HUB_LAUNCHES")) != 0;
     static const int n = getenv("SS_HUB_LEAD_BLOCKS") ? atoi(getenv("SS_HUB_LEAD_BLOCKS")) : kHubLeadBlocks;
-    return hubs && !launches ? (n >= 1 && n <= 65536 ? n : kHubLeadBlocks) : 0;
+    // (at least 4: the launches split the leading workgroups by integer division -- a quarter of them for the hop-1 HLL units, half
+    // for the MinHash units -- and every share must hold a workgroup)
+    return hubs && !launches ? (n >= 4 && n <= 65536 ? n : kHubLeadBlocks) : 0;
 }
 
 struct HubCounts {

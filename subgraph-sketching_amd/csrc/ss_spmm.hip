@@ -67,22 +67,25 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int64_t *__restric
 // per node (count, and the index of the LAST one: add_remaining_self_loops is a scatter assignment in edge order)
 struct GcnScan {
     int32_t not_unit;   // some weight differs from 1.0f
-    int32_t pad[63];
+    int32_t bad_ids;    // some endpoint lies outside [0, N) -- negative ids included: the groupings would wrap them torch-style, PyG does not
+    int32_t pad[62];
 };
 __global__ __launch_bounds__(256) void gcn_scan_edges_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
                                                              const float *__restrict__ w, int64_t E, int64_t N, GcnScan *__restrict__ scan,
                                                              int32_t *__restrict__ self_count, int32_t *__restrict__ last_self)
 {
-    bool odd = false;
+    bool odd = false, bad = false;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = row[e], c = col[e];
         odd |= w[e] != 1.0f;
+        bad |= (uint64_t)r >= (uint64_t)N || (uint64_t)c >= (uint64_t)N;
         if (r == c && (uint64_t)r < (uint64_t)N) {
             atomicAdd(&self_count[r], 1);
             atomicMax(&last_self[r], (int32_t)e);
         }
     }
     if (__ballot(odd) && (threadIdx.x & (kWave - 1)) == 0) scan->not_unit = 1;  // (plain store of the same value by whoever sees one)
+    if (__ballot(bad) && (threadIdx.x & (kWave - 1)) == 0) scan->bad_ids = 1;
 }
 
 // dinv / loop_w per node.  Unit weights (scan->not_unit == 0): deg = (entries of the column group - existing self loops) + loop weight,
@@ -155,18 +158,20 @@ __global__ __launch_bounds__(256) void sign_spmm_kernel(const int64_t *__restric
     const int64_t e0 = rowptr_r[i], e1 = rowptr_r[i + 1];
     const int CF = F >> 2;  // float4 chunks per row
     const float di = dinv[i];
-    const int c4 = cl < CF ? cl : 0;  // (F / 4 <= 64: one chunk per lane when lanes_per_row == pow2_ceil(F / 4); wider rows loop below)
-    float4 acc[1] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
     for (int cbase = 0; cbase < CF; cbase += lanes_per_row) {  // (one iteration unless F > 256)
-        const int c = cbase + c4;
+        // lanes past the last chunk (F / 4 not a multiple of the lane group: the padded Planetoid widths 1436, 3704, 500) read the last
+        // chunk and do not store -- in EVERY iteration (only the first one was clamped)
+        const int c = cbase + cl < CF ? cbase + cl : CF - 1;
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         for (int64_t j0 = e0; j0 < e1; j0 += lanes_per_row) {
             // this lane's entry of the stretch
             const int64_t j = j0 + cl;
             const int32_t e = order_r[j < e1 ? j : e0];
-            const int64_t my_c = col[e];
+            const int64_t raw_c = col[e];
+            const bool in_range = (uint64_t)raw_c < (uint64_t)N;  // (an id out of range is reported by ss_gcn_scan_edges; here it must only not be followed)
+            const int64_t my_c = in_range ? raw_c : i;
             const float my_nw = di * (unit ? 1.0f : w[e]) * dinv[my_c];
-            const int my_use = j < e1 && my_c != i;
+            const int my_use = j < e1 && in_range && my_c != i;
             const int n = (int)(e1 - j0 < lanes_per_row ? e1 - j0 : lanes_per_row);
             for (int k0 = 0; k0 < n; k0 += 4) {  // (uniform per row group)
                 float4 r[4];
@@ -198,7 +203,6 @@ __global__ __launch_bounds__(256) void sign_spmm_kernel(const int64_t *__restric
         a.w += rs.w * nl;
         if (i_raw < N && cbase + cl < CF) *reinterpret_cast<float4 *>(out + i * F + 4 * c) = a;
     }
-    (void)acc;
 }
 
 }  // namespace ss

@@ -30,7 +30,23 @@ _KNOBS = ('KERNEL_TIMER', 'GROUP_LINKS_MIN', 'GROUP_GATHER_MIN', 'LAZY_MINHASH',
           'REUSE_CSR_BY_CONTENT', 'FUSED_STAGE_MAX_TABLE_BYTES')
 
 
-def __getattr__(name):  # hashing.DEFER_TABLE_HOP etc. read the live value in knobs (set them THERE: knobs.X = ...)
+def __getattr__(name):  # hashing.DEFER_TABLE_HOP etc. read the live value in knobs
     if name in _KNOBS:
         return getattr(knobs, name)
     raise AttributeError(f'module {__name__!r} has no attribute {name!r}')
+
+
+class _ForwardingModule(type(knobs)):
+    """`hashing.LAZY_MINHASH = False` (how rounds 1-3 documented the switches) must keep working after the split: a write to one of
+    the former hashing.* switches goes to knobs, where the engine reads it -- not into a shadow attribute nobody looks at"""
+
+    def __setattr__(self, name, value):
+        if name in _KNOBS:
+            setattr(knobs, name, value)
+        else:
+            super().__setattr__(name, value)
+
+
+import sys as _sys  # noqa: E402
+
+_sys.modules[__name__].__class__ = _ForwardingModule

@@ -20,15 +20,18 @@ def csr_bytes(N, E):
 
 
 # random whole-row gathers of 512-byte rows against the size of the table they come from: tools/micro/gather_ceiling.hip on an
-# MI355X (profiles/round4_gather_ceiling.txt; best of its in-flight / grid / rows-per-item settings).  The
-# rate such an access pattern can reach -- Infinity-Cache resident below ~256 MB, HBM resident above.
-GATHER_CEILING_GBS = [(30e6, 8730.0), (60e6, 8120.0), (120e6, 7840.0), (200e6, 7700.0), (295e6, 7650.0), (600e6, 7550.0), (1500e6, 7090.0)]
+# MI355X (profiles/round4_gather_ceiling.txt; best of its in-flight / grid / rows-per-item settings), with the 4-byte id the probe
+# reads for every gathered row COUNTED (the tracked table counts rows only: x 516 / 512) -- a row kernel's algorithmic bytes
+# count its ids too.  Infinity-Cache resident below ~256 MB, HBM resident above.  A reference point for the access pattern, not a
+# bound: a kernel also streams finished rows out, which travel faster than gathers.
+GATHER_PROBE_GBS = [(30e6, 8730.0 * 516 / 512), (60e6, 8120.0 * 516 / 512), (120e6, 7840.0 * 516 / 512), (200e6, 7700.0 * 516 / 512),
+                    (295e6, 7650.0 * 516 / 512), (600e6, 7550.0 * 516 / 512), (1500e6, 7090.0 * 516 / 512)]
 
 
-def gather_ceiling_gbs(table_bytes):
-    """measured ceiling (GB/s) of random row gathers from a table of this size: log-linear interpolation of GATHER_CEILING_GBS"""
+def gather_probe_gbs(table_bytes):
+    """measured rate (GB/s) of random row gathers from a table of this size: log-linear interpolation of GATHER_PROBE_GBS"""
     import math
-    pts = GATHER_CEILING_GBS
+    pts = GATHER_PROBE_GBS
     if table_bytes <= pts[0][0]:
         return pts[0][1]
     if table_bytes >= pts[-1][0]:

@@ -119,7 +119,9 @@ def generate_sign_features(x, edge_index, edge_weight, sign_k):
                   'ss_gcn_degree')
     _native.check(lib.ss_sign_spmm(_ptr(rowptr_r), _ptr(order_r), _ptr(col), _ptr(w), _ptr(dinv), _ptr(loop_w), _ptr(scan), n, _ptr(xd), F + pad, _ptr(out),
                                    _stream(device)), 'ss_sign_spmm')
-    if int(err.item()):  # (the one host read of the chain)
+    # (the one host read of the chain) the groupings' flag, or ss_gcn_scan_edges' own word for ids outside [0, N) -- negative ones
+    # included, which the groupings wrap torch-style; the product kernel does not follow an id out of range
+    if int((err + scan[4:8].view(torch.int32)).item()):
         raise IndexError('edge_index refers to nodes outside [0, num_nodes)')
     ax = out[:, :F] if pad else out
     ax = ax if home == device else ax.to(home)

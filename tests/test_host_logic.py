@@ -269,7 +269,8 @@ def test_byte_model_of_the_step(ssa):
     assert rf.residency(576289, 'minhash_hop') == 'hbm' and rf.residency(576289, 'hll_hop') == 'infinity-cache'
     assert rf.unique_bytes(n, e, 'minhash_hop') == 2 * n * 512 + 4 * e + 8 * (n + 1)
     assert rf.csr_bytes(n, e) == 20 * e + 8 * (n + 1)               # algorithmic: edge list read once, col + rowptr written once
-    assert rf.gather_ceiling_gbs(120e6) == 7840.0 and 7090.0 < rf.gather_ceiling_gbs(1e9) < 7550.0 and rf.gather_ceiling_gbs(1e7) == 8730.0
+    ids = 516 / 512  # (the probe's id bytes counted)
+    assert rf.gather_probe_gbs(120e6) == 7840.0 * ids and 7090.0 * ids < rf.gather_probe_gbs(1e9) < 7550.0 * ids and rf.gather_probe_gbs(1e7) == 8730.0 * ids
     # ss_minhash_hop_rows over all N rows moves what the full table hop moves (+ an 8-byte row id and a second rowptr word per
     # listed row), over one ELPH batch 1.7 % of it
     assert abs(rf.minhash_rows_bytes(n, e, n) - (k['minhash_hop'] + 16 * n)) < 1e5

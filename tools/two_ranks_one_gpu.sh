@@ -4,5 +4,5 @@
 # both ranks on device 0 and gloo instead of RCCL -- the numbers mean nothing (two processes share one GPU, exchanges go through the
 # host); what it checks is that every collective of the N > 1 path is entered by every rank with matching shapes.
 cd $GRAFT_REPO_ROOT
-SS_BENCH_SINGLE_DEVICE=1 SS_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+SS_BENCH_SINGLE_DEVICE=1 SS_BENCH_BACKEND=gloo python \
   bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --sustain-seconds 0 "$@"
