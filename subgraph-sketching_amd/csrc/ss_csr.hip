@@ -60,12 +60,12 @@ constexpr int kRunCap = 1024;          // run descriptors the finish step keeps 
 // round 3 did: 61 us instead of 23 for the finish launch of a collab-size graph with rank^-0.5 endpoints.)
 constexpr int kDenseMin = kFinishCap;  // a fine bucket with more edges than this is split ...
 constexpr int kDensePart = 8192;       // ... into shares of about this many edges
-// dense_count words: [0] registered (dense) buckets, [1] shares, [2] the hint (registered buckets before it have no unclaimed share),
+// dense_count words: [0] registered (dense) buckets, [1] shares, [2] the hint (registered buckets before it have no unclaimed share), [3] spent buckets,
 // [kArriveBase + 16 k] (k < kArriveWords, one cache line each) fine buckets whose workgroup has decided -- 64 sharded words: one word
 // takes ~90 atomics per microsecond
 constexpr int kArriveBase = 16, kArriveWords = 64, kDenseSyncInts = kArriveBase + 16 * kArriveWords;
 struct DenseSync {     // per registered bucket, zeroed by the tile sort of the build
-    int32_t pub;       // 1: descriptor, share bounds and zeroed counters are visible
+    int32_t pub;       // != 0: descriptor, share bounds and zeroed counters are visible; the value is the bucket's number of shares
     int32_t next;      // count step: next share to claim (>= shares: none left)
     int32_t counted;   // shares whose count step is complete
     int32_t pnext;     // place step: next ticket for the shares whose counting workgroup moved on (orphans)
@@ -91,6 +91,8 @@ struct LevelPlan {
     int64_t tmax[kMaxLevels];       // tile slots of level l (row stride of its descriptor arrays)
     bool packed;                    // records of the last level are 4 bytes
     int src_bits;                   // 32 - node_shift
+    bool packed0;                   // two-level plans: the records of level 0 are 4 bytes too, src | (dst & (2^shift[0] - 1)) << src_bits0
+    int src_bits0;                  // 32 - shift[0]
 };
 
 inline int ceil_log2_i64(int64_t x)
@@ -122,6 +124,19 @@ inline bool make_plan(int64_t N, int64_t E, int64_t max_src, LevelPlan &p)
     p.levels = fine <= kMaxKeys ? 1 : (tb <= 16 ? 2 : 3);
     int below[kMaxLevels] = {0, 0, 0};  // key bits of the levels under level 0: split evenly (run lengths 4096 / keys per level)
     if (p.levels == 2) below[1] = tb / 2;
+    // two levels: inside a run of level 0 the top bits of dst ARE the run's key -- a record only needs src and the bits of dst below
+    // that key.  If those fit 32 bits with level 0 taking a few more key bits than half (<= 256 keys still), the level-0 records are
+    // written and read as 4 bytes instead of 8: 44 -> 36 bytes moved per edge (ogbl-ppa size: 20 + 12 bits)
+    bool packed0 = false;
+    if (p.levels == 2 && !getenv("SS_CSR_NO_PACK")) {
+        const int need = ceil_log2_i64(max_src > 1 ? max_src : 2);
+        for (int b1 = below[1]; b1 >= 1; --b1)  // fewer key bits at level 1 = more at level 0 = fewer low bits of dst in a record
+            if (need + node_shift + b1 <= 32 && ((n + ((int64_t)1 << (node_shift + b1)) - 1) >> (node_shift + b1)) <= kMaxKeys) {
+                below[1] = b1;
+                packed0 = true;
+                break;
+            }
+    }
     if (p.levels == 3) { below[2] = tb / 3; below[1] = (tb - below[2]) / 2; }
     int s = node_shift;
     for (int l = p.levels - 1; l >= 1; --l) {
@@ -143,6 +158,8 @@ inline bool make_plan(int64_t N, int64_t E, int64_t max_src, LevelPlan &p)
     }
     p.src_bits = 32 - node_shift;
     p.packed = max_src <= ((int64_t)1 << p.src_bits) && !getenv("SS_CSR_NO_PACK");  // (SS_CSR_NO_PACK: test hook, 8-byte records)
+    p.src_bits0 = 32 - p.shift[0];
+    p.packed0 = packed0 && p.packed && max_src <= ((int64_t)1 << p.src_bits0);
     return true;
 }
 
@@ -533,10 +550,12 @@ struct LevelOut {
 // of the parent group's tiles.  Thread i takes positions i, i + 512, ...: a wavefront's 64 positions share a 64-aligned block, whose
 // first run comes from a small table; the runs are <= kRegroupRuns descriptors in LDS (a chunk that spans more -- runs shorter
 // than 8 edges on average -- takes further rounds).  Then exactly tile_sort_kernel: LDS counting sort by the level's key.
-template <bool PACKED>
+// PACKED_IN (the parent is level 0 of a two-level plan whose records fit): 4-byte input records src | (dst low bits) << in_src_bits; the high
+// bits of dst are the group's key at level 0
+template <bool PACKED, bool PACKED_IN = false>
 __global__ __launch_bounds__(kRegroupThreads) __attribute__((amdgpu_waves_per_eu(8))) void regroup_sort_kernel(ParentLevel par, const int2 *__restrict__ staged_in,
                                                                        const uint32_t *__restrict__ prefix, LevelOut out,
-                                                                       const int32_t *__restrict__ skip)
+                                                                       const int32_t *__restrict__ skip, int in_src_bits = 0, int in_shift = 0)
 {
     __shared__ int2 sorted[kTile];
     __shared__ int32_t run_start[kRegroupRuns + 3];
@@ -603,8 +622,17 @@ __global__ __launch_bounds__(kRegroupThreads) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int k = 0; k < PER; ++k) rec[k] += run_delta[run[k]];
         int2 got[PER];
+        if (PACKED_IN) {
+            uint32_t got32[PER];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) got[k] = staged_in[rec[k]];
+            for (int k = 0; k < PER; ++k) got32[k] = reinterpret_cast<const uint32_t *>(staged_in)[rec[k]];
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                got[k] = make_int2((int)(got32[k] & ((1u << in_src_bits) - 1u)), (int)(((uint32_t)G << in_shift) | (got32[k] >> in_src_bits)));
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) got[k] = staged_in[rec[k]];
+        }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int p = (int)threadIdx.x + k * kRegroupThreads;
@@ -730,6 +758,7 @@ struct FinishLds {
 // Hand-offs follow cdna_hip_programming.md Guideline 16: producer stores -> barrier -> lane-0 agent release fence -> s_waitcnt
 // vmcnt(0) -> relaxed agent atomic; consumer relaxed poll -> agent acquire fence -> barrier.
 constexpr int kHintWord = 2;                                   // dense_count[2]: registered buckets before it have no unclaimed share
+constexpr int kSpentWord = 3;                                  // dense_count[3]: registered buckets whose last share has been taken
 constexpr unsigned long long kWaitTicks = 200000000ULL;        // wall_clock64 ticks (100 MHz): 2 s -- see wait_until
 constexpr unsigned long long kHelperPatienceTicks = 100000ULL;  // 1 ms: a dedicated helper that finds nothing for that long leaves
 
@@ -999,18 +1028,18 @@ struct DenseRunArgs {
     int t_lo, t_hi;
 
     // the registration is complete: publish it, then count this bucket's workgroup as arrived (G16 producer form)
-    __device__ __forceinline__ void publish(int d) const
+    __device__ __forceinline__ void publish(int d, int shares) const
     {
         __syncthreads();
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&sync[d].pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync[d].pub, shares, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&count[kArriveBase + 16 * (blockIdx.x % kArriveWords)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // the bucket's runs in tile order: a share ends behind the tile in which the running edge count crosses a multiple of kDensePart
-    __device__ __forceinline__ void register_bucket(FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int nb) const
+    __device__ __forceinline__ int register_bucket(FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int nb) const
     {
         const int shares = (int)((seg_n + kDensePart - 1) / kDensePart);
         if (threadIdx.x == 0) {
@@ -1052,13 +1081,14 @@ struct DenseRunArgs {
             if (s_hi != s_lo && s_hi < (uint32_t)shares) share_lo[first + s_hi] = (uint32_t)(t + 1);  // (a run is at most a tile: one crossing)
             carry += tot;
         }
-        publish(d);
+        publish(d, shares);
+        return d;
     }
     // the same registration from what RunEdges::prepare left in the registers of the bucket's workgroup (thread i: the position `ex`
     // of the run of tile t_lo + i * KPER and the lengths of its KPER runs): no second pass over the descriptors, no second scan
     // (rank^-0.5 endpoints at collab size: the dense buckets are registered 7.5 us into the launch instead of 12.5)
     template <int KPER>
-    __device__ __forceinline__ void register_from_prefix(FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int nb, uint32_t ex,
+    __device__ __forceinline__ int register_from_prefix(FinishLds &lds, unsigned long long seg_lo, uint32_t seg_n, int nb, uint32_t ex,
                                                          const uint32_t (&len)[KPER]) const
     {
         const int shares = (int)((seg_n + kDensePart - 1) / kDensePart);
@@ -1083,7 +1113,8 @@ struct DenseRunArgs {
             if (s_hi != s_lo && s_hi < (uint32_t)shares && t < t_hi) share_lo[first + s_hi] = (uint32_t)(t + 1);  // (a run is at most a tile: one crossing)
             ex = after;
         }
-        publish(d);
+        publish(d, shares);
+        return d;
     }
     // a bucket that is finished by its own workgroup has decided too (the dedicated helpers leave once every bucket has)
     __device__ __forceinline__ void arrive() const
@@ -1183,6 +1214,8 @@ __device__ __forceinline__ bool dense_help_bucket(DenseRunLds &lds, uint32_t *st
     for (;;) {
         const int s = take(&sy->next);
         if (s >= b.shares) break;  // workgroup-uniform
+        if (s == b.shares - 1 && threadIdx.x == 0)  // the bucket's last share: nobody needs to look at it again
+            __hip_atomic_fetch_add(&dense.count[kSpentWord], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (mine >= 0 && threadIdx.x == 0) {  // the records of the share before are about to be overwritten: somebody else places it
             __hip_atomic_store(&dense.claim[mine], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&sy->orphans, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (visible before this share's `counted`: release below)
@@ -1256,66 +1289,107 @@ __device__ __forceinline__ bool dense_help_bucket(DenseRunLds &lds, uint32_t *st
     return true;
 }
 
-// passes over the registered buckets, from the hint word on, until a pass finds nothing to do.  dedicated: a helper workgroup --
-// it keeps polling until every bucket workgroup has arrived (or its patience ends: it is an accelerator, not a participant anybody
-// depends on)
+// Looks over the registered buckets, 64 at a time (lane l of wave 0 takes bucket d0 + l), until a whole round over the windows finds
+// nothing to claim.  WHICH bucket of a window a workgroup goes for is drawn at random, weighted by the shares each bucket still
+// has to give: the first version sent everybody to the FIRST open bucket -- with 22 dense buckets (collab size, rank^-0.5) 128 helpers
+// queued through them one failed claim (~4 us: look, ticket, barriers) after the other, 84 us instead of 39 for the launch; with the
+// ~500 dense buckets of a ppa-size graph 1.3 ms instead of 0.21 -- and the window a round starts with is drawn too.
+// count[kSpentWord] counts the buckets whose last share has been taken: a workgroup that finds it equal to the number of registered
+// buckets has nothing to look for (one round trip at the end of every bucket workgroup of a skewed graph instead of a scan).
+// dedicated: a helper workgroup -- it keeps polling until every bucket workgroup has arrived (or its patience ends: it is an
+// accelerator, not a participant anybody depends on)
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+
 template <bool PACKED>
-__device__ __forceinline__ void dense_help(DenseRunLds &lds, uint32_t *stash, bool dedicated, int n_buckets, const DenseRunWork &w,
+__device__ __forceinline__ void dense_help(DenseRunLds &lds, uint32_t *stash, bool dedicated, int n_buckets, int own, const DenseRunWork &w,
                                            const RowOutputs &o, const DenseRunArgs &dense)
 {
     const unsigned long long t_start = dedicated ? wall_clock64() : 0ULL;
-    for (;;) {
+    uint32_t draws = blockIdx.x * 0x9E3779B9u;
+    int forced = own;  // own >= 0: this workgroup has just registered bucket `own` -- its first pick, without a look (ONE call site of dense_help_bucket: a second inlined copy costs 56 bytes of scratch)
+    for (;;) {  // rounds
         bool progress = false;
         __syncthreads();
         if (threadIdx.x == 0) {
             lds.unpublished = 0;
             lds.pick = __hip_atomic_load(&dense.count[kHintWord], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lds.n_dense = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lds.claim = __hip_atomic_load(&dense.count[kSpentWord], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        int d0 = lds.pick;
-        int spent_end = d0;  // (thread 0's copy counts) every registered bucket before it has no unclaimed share left
-        for (;;) {  // 64 registered buckets per look: lane l of wave 0 takes bucket d0 + l
-            __syncthreads();
-            if (threadIdx.x < kWave) {
-                const int lane = threadIdx.x;
-                const int n_dense = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int d = d0 + lane;
-                const int pub = d < n_dense ? __hip_atomic_load(&dense.sync[d].pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const int shares = pub ? __hip_atomic_load(const_cast<int32_t *>(&w.list[d].shares), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                const int nxt = pub ? __hip_atomic_load(&dense.sync[d].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                const unsigned long long open = __ballot(pub && nxt < shares);
-                const unsigned long long unpub = __ballot(d < n_dense && !pub);
-                const unsigned long long spent = __ballot(pub && nxt >= shares);
-                if (lane == 0) {
-                    lds.pick = open ? d0 + __builtin_ctzll(open) : -1;
-                    lds.n_dense = n_dense;
-                    if (unpub) lds.unpublished = 1;
-                    // the leading buckets of this look that have no unclaimed share left, if everything before the look is in the same
-                    // state: later passes (anybody's) start behind them
-                    const int lead = ~spent ? __builtin_ctzll(~spent) : kWave;
-                    if (d0 == spent_end && lead > 0) {
-                        spent_end = d0 + lead;
-                        atomicMax(&dense.count[kHintWord], spent_end);
+        const int hint = lds.pick, registered = lds.n_dense, spent = lds.claim;
+        if (spent < registered) {  // (workgroup-uniform) something may be left to claim
+            const int windows = (registered - hint + kWave - 1) / kWave;
+            const int w0 = windows > 1 ? (int)(mix32(draws += 0x632BE5ABu) % (uint32_t)windows) : 0;
+            int spent_end = hint;  // (thread 0's copy counts) every registered bucket before it has no unclaimed share left
+            int idle = 0, win = w0;  // windows in a row without anything to claim; the window being looked at
+            for (int guard = 0; idle < windows && guard < 64 * windows + 64; ++guard) {  // (the second bound: a round of lost draws ends, the next begins)
+                const int d0 = hint + kWave * win;
+                const uint32_t draw = mix32(draws += 0x632BE5ABu);
+                __syncthreads();
+                if (forced >= 0) {  // (workgroup-uniform)
+                    if (threadIdx.x == 0) lds.pick = forced;
+                    forced = -1;
+                } else if (threadIdx.x < kWave) {
+                    const int lane = threadIdx.x;
+                    const int n_dense = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int d = d0 + lane;
+                    // two independent loads, one round trip: the published word IS the bucket's share count, and its claim counter has
+                    // been zero since the tile sort of this build
+                    const int shares = d < n_dense ? __hip_atomic_load(&dense.sync[d].pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    const int nxt = d < n_dense ? __hip_atomic_load(&dense.sync[d].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (before anybody reads the descriptor of a bucket picked here)
+                    const bool pub = shares != 0;
+                    const int left = pub && nxt < shares ? shares - nxt : 0;  // shares this bucket still has to give
+                    int inc = left;
+#pragma unroll
+                    for (int off = 1; off < kWave; off <<= 1) {
+                        const int x = __shfl_up(inc, off);
+                        if (lane >= off) inc += x;
+                    }
+                    const int total = __shfl(inc, kWave - 1);
+                    // the bucket whose stretch of the running sum holds the draw: a workgroup lands on a bucket with probability
+                    // proportional to what is left there
+                    const int x = total > 0 ? (int)(draw % (uint32_t)total) : 0;
+                    const unsigned long long here = __ballot(left > 0 && inc > x);
+                    const unsigned long long unpub = __ballot(d < n_dense && !pub);
+                    const unsigned long long done = __ballot(pub && nxt >= shares);
+                    if (lane == 0) {
+                        lds.pick = total > 0 ? d0 + __builtin_ctzll(here) : -1;
+                        if (unpub) lds.unpublished = 1;
+                        // the leading buckets of this window that have no unclaimed share left, if everything before the window is in
+                        // the same state: later rounds (anybody's) start behind them
+                        const int lead = ~done ? __builtin_ctzll(~done) : kWave;
+                        if (d0 == spent_end && lead > 0) {
+                            spent_end = d0 + lead;
+                            atomicMax(&dense.count[kHintWord], spent_end);
+                        }
                     }
                 }
+                __syncthreads();
+                const int pick = lds.pick;
+                if (pick < 0) {
+                    ++idle;
+                    win = win + 1 < windows ? win + 1 : 0;
+                    continue;
+                }
+                if (dense_help_bucket<PACKED>(lds, stash, pick, w, o, dense)) progress = true;
+                idle = 0;  // (the same window again while it has something to give)
             }
-            __syncthreads();
-            const int pick = lds.pick, n_dense = lds.n_dense;
-            if (pick < 0) {
-                if (d0 + kWave >= n_dense) break;
-                d0 += kWave;
-                continue;
-            }
-            progress |= dense_help_bucket<PACKED>(lds, stash, pick, w, o, dense);
-            if (spent_end == pick) spent_end = pick + 1;  // (that bucket's claim counter has run out)
-            d0 = pick + 1;
         }
         if (!dedicated) {
             if (!progress) return;  // a bucket registered later is worked off by its own workgroup and whoever finishes after it
             continue;
         }
-        // a dedicated helper: done once every bucket workgroup has decided and a pass found nothing to claim
+        // a dedicated helper: done once every bucket workgroup has decided and a round found nothing to claim
         __syncthreads();
         if (threadIdx.x < kWave) {
             int v = __hip_atomic_load(&dense.count[kArriveBase + 16 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1352,6 +1426,7 @@ __global__ __launch_bounds__(kRunThreads) __attribute__((amdgpu_waves_per_eu(4, 
     DenseRunLds &help_lds = *reinterpret_cast<DenseRunLds *>(lds.image);
     uint32_t *help_stash = reinterpret_cast<uint32_t *>(lds.image) + kHelperStashWord;
     const bool dedicated = (int64_t)blockIdx.x >= fine_buckets;  // a helper workgroup: no bucket of its own
+    int own = -1;                                                // the registered bucket of this workgroup, if its bucket is dense
     // ONE call site of dense_help at the end of the kernel (three inlined copies: 166 VGPRs, one workgroup per CU instead of two)
     if (!dedicated) {
     SS_TICK_START();
@@ -1421,8 +1496,7 @@ __global__ __launch_bounds__(kRunThreads) __attribute__((amdgpu_waves_per_eu(4, 
     SS_TICK(0);
     const int nb = 1 << node_shift;  // <= 1024 nodes
     if (n > (uint32_t)kDenseMin) {  // (workgroup-uniform) does not fit the image: registered, then worked off share by share by everybody
-        if (announced) dense.register_from_prefix(lds, base, n, nb, sc.ex, sc.len);
-        else dense.register_bucket(lds, base, n, nb);
+        own = announced ? dense.register_from_prefix(lds, base, n, nb, sc.ex, sc.len) : dense.register_bucket(lds, base, n, nb);
         SS_MARK(14);
     } else {
     if (!announced) dense.arrive();
@@ -1445,7 +1519,8 @@ __global__ __launch_bounds__(kRunThreads) __attribute__((amdgpu_waves_per_eu(4, 
     SS_TICK(2);
     // anything registered by now?  Loaded here, used behind the bucket's last stores (the load's latency hides under the placing
     // sweep); a bucket registered later than this look is worked off by its own workgroup and by whoever finishes later
-    const int registered = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int registered = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                           __hip_atomic_load(&dense.count[kSpentWord], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (registered, not yet given away)
     auto place = [&](int x, int y) { lds.image[atomicAdd(&cnt[y], 1u)] = x; };
     if (stashed) edges.replay(stash, n, place);
     else edges.for_each(place);
@@ -1456,10 +1531,10 @@ __global__ __launch_bounds__(kRunThreads) __attribute__((amdgpu_waves_per_eu(4, 
     SS_TICK(4);
     SS_MARK(9);
     __syncthreads();  // the image is free (it becomes the helper's LDS), the look is visible
-    if (red_n[0] == 0) return;  // every unskewed graph
+    if ((int)red_n[0] <= 0) return;  // every unskewed graph; a skewed one whose dense buckets have all been taken
     }
     }
-    dense_help<PACKED>(help_lds, help_stash, dedicated, (int)fine_buckets, work, o, dense);
+    dense_help<PACKED>(help_lds, help_stash, dedicated, (int)fine_buckets, own, work, o, dense);
     SS_MARK(13);
 }
 
@@ -1725,7 +1800,10 @@ static int csr_build_launch(const ss::LevelPlan &lp, const int64_t *src, const i
     unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
     const int tiles0 = (int)lp.tmax[0];
     const bool packed = lp.packed;  // records of the last level (read by the finish step) are 4 bytes
-    if (packed && lp.levels == 1)
+    if (lp.packed0)  // (two levels: 4-byte level-0 records, see make_plan)
+        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(tiles0), dim3(kSortThreads), 0, stream, src, dst, E, N, key_stride, lp.shift[0], lp.src_bits0, lp.keys[0],
+                           tiles0, (void *)w.staged_a, w.lv[0].off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, w.dense_sync, (int)max_dense_buckets(E), skip, bad_record);
+    else if (packed && lp.levels == 1)
         hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(tiles0), dim3(kSortThreads), 0, stream, src, dst, E, N, key_stride, lp.shift[0], lp.src_bits, lp.keys[0],
                            tiles0, (void *)w.staged_a, w.lv[0].off, w.tile_max, err_flag, hub_count, mega_count, w.dense_count, w.dense_sync, (int)max_dense_buckets(E), skip, bad_record);
     else
@@ -1748,7 +1826,10 @@ static int csr_build_launch(const ss::LevelPlan &lp, const int64_t *src, const i
         const bool last = l == lp.levels - 1;
         const LevelOut out = {out_buf, a.off, a.tstart, a.header, a.n_tiles, (int)lp.tmax[l], lp.keys[l], lp.shift[l], lp.src_bits,
                               (1 << lp.node_shift) - 1};
-        if (last && packed)
+        if (l == 1 && lp.packed0)
+            hipLaunchKernelGGL((regroup_sort_kernel<true, true>), dim3((unsigned)lp.tmax[l]), dim3(kRegroupThreads), 0, stream, par,
+                               (const int2 *)in, w.lv[l - 1].prefix, out, skip, lp.src_bits0, lp.shift[0]);
+        else if (last && packed)
             hipLaunchKernelGGL(regroup_sort_kernel<true>, dim3((unsigned)lp.tmax[l]), dim3(kRegroupThreads), 0, stream, par,
                                (const int2 *)in, w.lv[l - 1].prefix, out, skip);
         else
