@@ -173,6 +173,27 @@ def roofline_numbers(rf, bytes_alg, launch_ms, table_bytes, traffic):
                                  '(profiles/round4_gather_ceiling.txt, id bytes counted): a reference point for this access pattern, not a bound'}
 
 
+def emit(out):
+    """print the ONE line.  Order: the contract's keys, then a compact summary of the secondary shapes (name -> ms_per_step, fraction of
+    the HBM peak of the dominant kernel, where its table lives) -- the long objects come last, so that a reader who keeps only the
+    head of the line (the driver's record does) still sees the ELPH step and the HBM-resident shapes (VERDICT r4 weak #8)"""
+    head = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_cold', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'settle_seconds', 'settle_steps', 'rccl_ranks', 'backend', 'build', 'build_probe_ms_per_step']
+    line = {k: out[k] for k in head if k in out}
+    if 'secondary' in out:
+        line['secondary_summary'] = {name: ({'ms_per_step': round(row['ms_per_step'], 4),
+                                             'frac': round(row['dominant_frac_of_hbm_peak'], 3) if row.get('dominant_frac_of_hbm_peak') else None,
+                                             'kernel': row.get('dominant_kernel'), 'resident': row.get('resident'),
+                                             'Mpairs_per_s': round(row['pairs_per_s'] / 1e6, 1)}
+                                            if isinstance(row, dict) and 'ms_per_step' in row else row)
+                                     for name, row in out['secondary'].items() if name != 'note'}
+    for k in ('weak', 'same_work_speedup'):
+        if k in out:
+            line[k] = out[k]
+    line.update({k: v for k, v in out.items() if k not in line})
+    print(json.dumps(line), flush=True)
+
+
 def resident_label(rf, table_bytes):
     """where the gathered table lives, from the share of it the 256 MiB Infinity Cache can hold: all of it / most of it / little of it"""
     f = rf.cache_resident_fraction(table_bytes)
@@ -535,25 +556,14 @@ def main():
             t = float(tmax.item())
         return t
 
-    # N > 1, --build auto: which build serves THIS job fastest on this node (every rank the whole table / rows sharded + exchange per
-    # hop / rows sharded, written straight into the peers' tables) -- a few steps each, the max over ranks decides (all ranks agree)
+    # N > 1, --build auto: the timed region below runs with the REPLICATED build -- the one mode whose only collective is the gather of
+    # the feature rows -- so that a line exists whatever the node does with the others; the row-sharded and peer-write builds are
+    # timed with the same protocol AFTER it, under the watchdog of the strong-scaling figures, and the headline moves to the
+    # fastest mode only if one of them beat it (`build`, `build_probe_ms_per_step` say which and by how much)
     build_probe = None
-    if mode['build'] == 'auto':
-        build_probe, candidates = {}, ['replicated', 'sharded'] + ([] if a.no_strong_peer or a.api == 'elph' else ['peer'])
-        if a.api == 'elph':
-            candidates = ['replicated']  # (the ELPH call sequence drives the propagation objects itself: nothing to shard here)
-        for cand in candidates:
-            mode['build'] = cand
-            try:
-                for _ in range(3):
-                    step()
-                build_probe[cand] = 1e3 * timed_region(5) / 5
-            except Exception as exc:  # (PeerShard fails on every rank or on none: no peer access, no IPC)
-                build_probe[cand] = f'unavailable: {type(exc).__name__}: {str(exc)[:200]}'
-        timed = {k: v for k, v in build_probe.items() if isinstance(v, float)}
-        mode['build'] = min(timed, key=timed.get) if timed else 'replicated'
-        if mode['build'] != 'peer':
-            peer_state['shard'] = None
+    auto_build = mode['build'] == 'auto'
+    if auto_build:
+        mode['build'] = 'replicated'
     sharded_build = mode['build'] in ('sharded', 'peer')
 
     # the driver's protocol as a fresh process meets it (its --warmup steps, then its --steps), BEFORE anything has settled: printed
@@ -789,11 +799,27 @@ def main():
             if rank == 0:
                 out['strong'] = {'error': f'strong-scaling figures did not finish within {a.strong_timeout:.0f} s; skipped'}
                 out['cpu_baseline'] = None
-                print(json.dumps(out), flush=True)
+                emit(out)
             os._exit(0)
         watchdog = threading.Timer(a.strong_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
+        if auto_build:  # the other build modes on the headline's own job and protocol (see above)
+            build_probe = {'replicated': ms_per_step}
+            out['build_probe_ms_per_step'] = build_probe
+            for cand in ['sharded'] + ([] if a.no_strong_peer else ['peer']):
+                mode['build'] = cand
+                try:
+                    for _ in range(max(3, a.warmup)):
+                        step()
+                    t = timed_region(a.steps)
+                    build_probe[cand] = 1e3 * t / a.steps
+                    if build_probe[cand] < out['ms_per_step']:
+                        out.update(ms_per_step=build_probe[cand], value=pairs_per_step * a.steps / t, build=cand)
+                        out['config']['parallelism'] += f' -- headline re-timed with the {cand} build, which beat the replicated one on this node'
+                except Exception as exc:  # (PeerShard fails on every rank or on none: no peer access, no IPC)
+                    build_probe[cand] = f'unavailable: {type(exc).__name__}: {str(exc)[:200]}'
+            mode['build'] = out['build']
         try:
             out['strong'] = strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank, with_peer=not a.no_strong_peer)
         except Exception as exc:  # (deterministic failures are the same on every rank; the headline line must survive)
@@ -834,22 +860,7 @@ def main():
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:
-        # order of the line: the contract's keys, then a compact summary of the secondary shapes (name -> ms_per_step, fraction of the HBM
-        # peak of the dominant kernel, where its table lives) -- the long objects come last, so that a reader who keeps only the head of
-        # the line (the driver's record does) still sees the ELPH step and the HBM-resident shapes
-        head = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_cold', 'higher_is_better', 'scaling', 'vs_baseline',
-                'dtype', 'data', 'settle_seconds', 'settle_steps', 'rccl_ranks', 'backend', 'build', 'build_probe_ms_per_step']
-        line = {k: out[k] for k in head if k in out}
-        if 'secondary' in out:
-            line['secondary_summary'] = {name: ({'ms_per_step': round(row['ms_per_step'], 4), 'frac': round(row['dominant_frac_of_hbm_peak'], 3) if row.get('dominant_frac_of_hbm_peak') else None,
-                                                 'kernel': row.get('dominant_kernel'), 'resident': row.get('resident'), 'Mpairs_per_s': round(row['pairs_per_s'] / 1e6, 1)}
-                                                if isinstance(row, dict) and 'ms_per_step' in row else row)
-                                         for name, row in out['secondary'].items() if name != 'note'}
-        for k in ('weak', 'same_work_speedup'):
-            if k in out:
-                line[k] = out[k]
-        line.update({k: v for k, v in out.items() if k not in line})
-        print(json.dumps(line))
+        emit(out)
     if launched:
         dist.destroy_process_group()
 
