@@ -194,10 +194,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void h
     // rowptr and never look at it: a load under `if (l < deg)` is awaited with vmcnt(0) at the end of its branch, which put
     // the four rows' id loads one round trip behind the other)
     const int32_t *always_valid = reinterpret_cast<const int32_t *>(g.rowptr);
+    // ... of the first TWO rows; the first ids of row r + 2 are requested when row r is about to be walked.  (All four up front, as
+    // rounds 2-4 had it: the line a later row's first ids sit in also holds its next ids, and by the time a lane group has walked
+    // three rows of 74 neighbours -- ogbl-ppa -- that line has left the L2 again and is fetched a second time: PMC 0.398 GB for
+    // 0.324 GB algorithmic at that size against 1.03x at collab size, where four rows span two lines; VERDICT r4 #5.)
 #pragma unroll
-    for (int r = 0; r < kHllRows; ++r) nid0[r] = *(l < degs[r] ? g.col + rbs[r] + l : always_valid);
+    for (int r = 0; r < kHllRows; ++r) nid0[r] = r < 2 ? *(l < degs[r] ? g.col + rbs[r] + l : always_valid) : 0;
 #pragma unroll
     for (int r = 0; r < kHllRows; ++r) {
+        if (r + 2 < kHllRows) nid0[r + 2] = *(l < degs[r + 2] ? g.col + rbs[r + 2] + l : always_valid);
         const bool ok = oks[r];
         const int64_t i = ok ? first + r : g.row1 - 1;
         const int deg = degs[r];
