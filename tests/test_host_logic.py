@@ -439,3 +439,37 @@ def test_bias_table_sensitivity_bound(ssa):
     assert 0 < d_cards <= s * (1 + 1e-5), d_cards                      # the mean of six entries moves by at most what the entries do
     assert d_cards / cards0[~on_lc].min() < 0.01                       # < 1 % of any bias-branch cardinality
     assert 0 < d_feat <= 2 * s, d_feat                                 # a feature: differences of Jaccard-weighted union estimates and cards
+
+
+def test_peer_shard_slab_layout_and_pool_release(ssa):
+    """dist.PeerShard keeps ONE allocation per shard: _SlabLayout carves the 2 h + 1 tables out of it (256-byte aligned, the shapes
+    and dtypes the kernels expect, no overlap), and a dropped shard's slab goes back to the per-shape pool only if no tensor handed
+    out by its builds is still alive -- otherwise it is set aside for good (a later shard must not overwrite a table somebody kept)"""
+    D = ssa.dist
+    L = D._SlabLayout(1001, 3, 128, 256)
+    slab = torch.zeros(L.bytes, dtype=torch.uint8)
+    mh, hll, cards = L.views(slab)
+    assert [tuple(t.shape) for t in mh] == [(1001, 128)] * 3 and all(t.dtype == torch.int32 and t.is_contiguous() for t in mh)
+    assert [tuple(t.shape) for t in hll] == [(1001, 256)] * 3 and all(t.dtype == torch.uint8 for t in hll)
+    assert tuple(cards.shape) == (1001, 3) and cards.dtype == torch.float32
+    ptrs = sorted((t.data_ptr() - slab.data_ptr(), t.numel() * t.element_size()) for t in mh + hll + [cards])
+    assert all(off % 256 == 0 for off, _ in ptrs) and all(a + n <= b for (a, n), (b, _) in zip(ptrs, ptrs[1:])) and ptrs[-1][0] + ptrs[-1][1] <= L.bytes
+    for k, t in enumerate(mh + hll):
+        t.fill_(k + 1)
+    cards.fill_(0.5)
+    mh2, hll2, cards2 = L.views(slab)  # (what a peer carves out of the mapped slab)
+    assert all(int(t[7, 5]) == k + 1 for k, t in enumerate(mh2 + hll2)) and float(cards2[1000, 2]) == 0.5
+    # release: pooled when nothing else refers to the slab's storage, set aside when a view survives the shard
+    key = ('test', L.bytes, 'cpu')
+    D._POOL.pop(key, None)
+    before = len(D._QUARANTINE)
+    del mh, hll, cards, mh2, hll2, cards2, t
+    D._release_entry(key, {'id': 1, 'slab': slab, 'peers': {}})
+    assert len(D._POOL[key]) == 1 and len(D._QUARANTINE) == before
+    slab_b = torch.zeros(L.bytes, dtype=torch.uint8)
+    kept = L.views(slab_b)[2]  # the caller kept `cards` of a build through the shard it dropped
+    D._release_entry(key, {'id': 2, 'slab': slab_b, 'peers': {}})
+    assert len(D._POOL[key]) == 1 and len(D._QUARANTINE) == before + 1
+    del kept
+    D._POOL.pop(key, None)
+    D._QUARANTINE.pop()
