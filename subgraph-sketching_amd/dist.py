@@ -232,7 +232,9 @@ class PeerShard(RowShard):
         self.mh, self.hll, self.cards = self._carve.views(self._slab)
         self._order = [r for r in range(self.world) if r != self.rank]
         import weakref
-        weakref.finalize(self, _release_entry, key, entry)  # the slab and its mappings outlive the shard
+        # (the finaliser runs BEFORE the shard's own attributes are cleared: its views of the slab are still alive then, so "no tensor
+        # of a build is left" means "the storage has as many users as right now")
+        weakref.finalize(self, _release_entry, key, entry, _storage_users(self._slab))  # the slab and its mappings outlive the shard
         self.generation = 0
         self.hop_barrier()  # nobody starts storing into a table before everybody has mapped (and probed) it
 
@@ -363,11 +365,17 @@ _POOL_IDS = {}    # same key -> entries created so far
 _QUARANTINE = []  # slabs / mappings of constructions that failed: never reused, never freed (their memory must not be recycled)
 
 
-def _release_entry(key, entry):
+def _storage_users(t):
+    """tensors / storage handles that share t's memory right now (the temporary handle of this call included)"""
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+def _release_entry(key, entry, users_of_the_shard_itself):
     """a shard has been dropped: its slab goes back to the pool -- unless tensors handed out by its builds are still alive (the
-    caller kept a table but not the shard): that slab is then kept aside for good, a later shard must not overwrite the table"""
+    caller kept a table but not the shard): that slab is then kept aside for good, a later shard must not overwrite the table.
+    users_of_the_shard_itself: _storage_users(slab) when the shard stood complete (the slab + the shard's own views)"""
     try:
-        in_use = torch._C._storage_Use_Count(entry['slab'].untyped_storage()._cdata) > 2  # (the slab itself + the handle just made)
+        in_use = _storage_users(entry['slab']) > users_of_the_shard_itself
     except Exception:  # noqa: BLE001  (interpreter shutdown, a torch without the hook)
         in_use = True
     (_QUARANTINE if in_use else _POOL.setdefault(key, [])).append(entry)

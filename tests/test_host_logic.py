@@ -464,11 +464,22 @@ def test_peer_shard_slab_layout_and_pool_release(ssa):
     D._POOL.pop(key, None)
     before = len(D._QUARANTINE)
     del mh, hll, cards, mh2, hll2, cards2, t
-    D._release_entry(key, {'id': 1, 'slab': slab, 'peers': {}})
+
+    class Shard(object):  # what PeerShard does with its slab: own views as attributes, a finaliser that knows how many users that makes
+        def __init__(self, slab_, ident):
+            import weakref
+            self.slab = slab_
+            self.mh, self.hll, self.cards = L.views(slab_)
+            weakref.finalize(self, D._release_entry, key, {'id': ident, 'slab': slab_, 'peers': {}}, D._storage_users(slab_))
+
+    shard = Shard(slab, 1)
+    table = [shard.mh[0], shard.cards]  # what a build hands out
+    del table, shard                    # (the finaliser runs while the shard's own views are still alive: they must not count)
     assert len(D._POOL[key]) == 1 and len(D._QUARANTINE) == before
     slab_b = torch.zeros(L.bytes, dtype=torch.uint8)
-    kept = L.views(slab_b)[2]  # the caller kept `cards` of a build through the shard it dropped
-    D._release_entry(key, {'id': 2, 'slab': slab_b, 'peers': {}})
+    shard = Shard(slab_b, 2)
+    kept = shard.cards[:10]  # the caller kept a piece of `cards` of a build through the shard it dropped
+    del shard
     assert len(D._POOL[key]) == 1 and len(D._QUARANTINE) == before + 1
     del kept
     D._POOL.pop(key, None)
