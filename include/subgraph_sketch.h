@@ -138,6 +138,18 @@ int ss_csr_build(const int64_t *src, const int64_t *dst, int64_t E, int64_t N, i
                  int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count,
                  int32_t *mega_rows, int32_t *mega_count,
                  int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream);
+/* Failure of a build that was launched (every entry point that runs the builder: ss_csr_build, ss_csr_build_cached,
+ * ss_group_links_by_source, ss_csr_group_ids).  Buckets too dense for one workgroup are worked off in shares by several workgroups of
+ * the finish launch; the one cross-workgroup wait of that protocol is bounded (~2 s: it can only end late when the process is
+ * descheduled for seconds).  A wait that gives up leaves the outputs INCOMPLETE and is reported, never silently:
+ *   - bit 1 (SS_CSR_ERR_PROTOCOL) of *err_flag, when a flag was given (bit 0 = an endpoint outside [0, N), as before: test the bits);
+ *   - ss_csr_protocol_faults(): 0 while no wait of this process (any device, any stream) has given up; afterwards a positive stamp
+ *     that CHANGES with every further one.  Kept in pinned host memory and read WITHOUT synchronising -- compare before / after a
+ *     synchronised build, or poll it as the host mirror does (ElphHashes.check_errors and every later call raise RuntimeError).
+ *     -1: the word could not be allocated (no device). */
+#define SS_CSR_ERR_BOUNDS 1
+#define SS_CSR_ERR_PROTOCOL 2
+int ss_csr_protocol_faults(void);
 /* ss_csr_build preceded by a device-side content check: `fingerprint` (device buffer of SS_CSR_FINGERPRINT_BYTES, zeroed by the
  * caller before its first use and tied to THESE output buffers) holds two 64-bit sums over the edge list the outputs were last
  * built from; when the sums of (src, dst) agree every kernel of the build exits at once, otherwise the build runs and the sums are
@@ -293,6 +305,13 @@ int ss_gcn_degree(const int64_t *rowptr_c, const int32_t *order_c, const int64_t
                   float *dinv, float *loop_w, void *stream);
 int ss_sign_spmm(const int64_t *rowptr_r, const int32_t *order_r, const int64_t *col, const float *w, const float *dinv,
                  const float *loop_w, const void *scan, int64_t N, const float *x, int32_t F, float *out, void *stream);
+
+/* 128-bit content digest of a device buffer (bytes % 16 == 0, 16-byte aligned): out[0] = sum, out[1] = xor over its 16-byte chunks
+ * of a 64-bit mix of (chunk, chunk index) -- order-independent to compute, position-dependent in value.  out: device uint64[2],
+ * overwritten (the call clears it first).  One streaming pass at HBM rate.  For the multi-GPU builds: the reference has ONE
+ * table (hashing.py:139-165); a build that leaves a replica on every rank -- above all the peer-write build, whose rows arrive
+ * through other GPUs' stores -- compares the digests of all replicas after its first build (dist.verify_replicas). */
+int ss_table_digest(const void *data, int64_t bytes, uint64_t *out, void *stream);
 
 /* int64 <-> packed uint32 MinHash tables (the reference's tensors are int64, hashing.py:124). */
 int ss_pack_minhash(const int64_t *in, uint32_t *out, int64_t count, void *stream);

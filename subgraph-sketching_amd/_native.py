@@ -14,6 +14,7 @@ SS_MAX_HOPS = 3
 SS_MAX_TABLE = 512
 SS_FLAG_USE_ZERO_ONE = 1
 SS_FLAG_FLOOR_SF = 2
+SS_CSR_ERR_BOUNDS, SS_CSR_ERR_PROTOCOL = 1, 2  # bits of a CSR build's err_flag
 
 
 class HllParams(ctypes.Structure):
@@ -33,7 +34,7 @@ class CsrGraphStruct(ctypes.Structure):
                 ('mirror_cards', c_void_p * 7), ('hub_report', c_void_p), ('report_hub_count', c_void_p), ('report_mega_count', c_void_p)]
 
 
-ABI_VERSION = 128  # ss_version() of the library this module's struct mirrors and signatures describe
+ABI_VERSION = 129  # ss_version() of the library this module's struct mirrors and signatures describe
 PROF_MINHASH_HOP, PROF_HLL_HOP, PROF_FIRST_HOP_MH, PROF_FIRST_HOP_HLL, PROF_PAIRS, PROF_CSR, PROF_HUB, PROF_FUSED, PROF_MINHASH_ROWS = range(9)  # SS_PROF_* tags
 MEGA_DESC_WORDS = 8  # SS_MEGA_DESC_WORDS
 MEGA_SLICE, MEGA_SLOT_BYTES, CSR_FINGERPRINT_BYTES, MAX_MIRRORS = 1024, 1280, 8448, 7  # SS_MEGA_SLICE / SS_MEGA_SLOT_BYTES of include/subgraph_sketch.h
@@ -83,6 +84,8 @@ SIGNATURES = {
     'ss_gcn_scan_edges': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     'ss_gcn_degree': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ss_sign_spmm': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
+    'ss_csr_protocol_faults': (c_int32, []),
+    'ss_table_digest': (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
     'ss_pack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_unpack_minhash': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'ss_profile_enable': (c_int32, [c_uint32]),

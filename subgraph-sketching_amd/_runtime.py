@@ -74,6 +74,30 @@ def _take_error(device):
     return bad
 
 
+_FAULTS_REPORTED = [0]
+
+
+class CsrProtocolFault(RuntimeError):
+    """a CSR build (ss_csr_build*, ss_group_links_by_source, ss_csr_group_ids) gave up a cross-workgroup wait after its ~2 s bound:
+    its outputs are incomplete.  Only a process descheduled for seconds can cause it (csrc/ss_csr.hip "who may wait for whom")."""
+
+
+def raise_csr_protocol_faults():
+    """non-waiting look at the library's process-wide count of given-up waits (pinned host memory, ss_csr_protocol_faults): raises
+    once for every increase -- from the next call into the engine after the failed build completed, or from check_errors()"""
+    n = _native.lib().ss_csr_protocol_faults()  # 0: none so far; a stamp that changes with every further one; -1: no device
+    if n > 0 and n != _FAULTS_REPORTED[0]:
+        _FAULTS_REPORTED[0] = n
+        raise CsrProtocolFault(f'a cross-workgroup wait of a CSR build gave up after its time bound: the adjacency / link grouping '
+                               f'that build produced is INCOMPLETE and everything computed from it since is wrong -- rebuild (this '
+                               f'happens only when the process is descheduled for seconds: a debugger, a heavily oversubscribed GPU)')
+
+
+def mark_csr_protocol_faults_reported():
+    """the caller is about to raise for a fault it saw in a build's own err_flag: the library's word says nothing new"""
+    _FAULTS_REPORTED[0] = _native.lib().ss_csr_protocol_faults()
+
+
 _LIVE_DEFERRED = weakref.WeakSet()
 
 
@@ -118,13 +142,19 @@ class _DeferredErrors(object):
             if int(flag[0]):
                 if not synchronize:  # the word is only cleared once nothing in flight can still write it
                     torch.cuda.synchronize(torch.device(key))
+                bits = int(flag[0])
                 flag.zero_()
                 calls, self._calls = ', '.join(self._calls), []
+                if bits & _native.SS_CSR_ERR_PROTOCOL:  # (bit 1 of a CSR build's err_flag; bit 0 = ids out of range)
+                    mark_csr_protocol_faults_reported()
+                    raise CsrProtocolFault(f'a CSR build on this engine gave up a cross-workgroup wait (its adjacency is incomplete); calls '
+                                           f'since the last clean check: {calls}')
                 raise IndexError(f'an earlier call on this engine was given node ids outside its num_nodes (reported late: '
                                  f'strict_bounds="deferred"); calls since the last clean check: {calls}. Out-of-range edges '
                                  f'were dropped and out-of-range pairs returned NaN rows')
         if synchronize:
             self._calls = []
+        raise_csr_protocol_faults()
 
 
 def _check_sizes(num_perm, p):

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _native, hll_tables, knobs
-from ._runtime import _Span, _error_flag, _ptr, _stream
+from ._runtime import CsrProtocolFault, mark_csr_protocol_faults_reported, _Span, _error_flag, _ptr, _stream
 
 
 def default_hub_threshold(num_edges):
@@ -154,6 +154,9 @@ def build_csr(edge_index, num_nodes, device, check=True, hub_threshold=None, err
         # the one synchronising read of strict mode brings the hub / mega row counts along: a graph without such rows
         # (every unskewed graph) then serves no hub units (leading workgroups that would find nothing to do)
         host = flags32.cpu()
+        if int(host[3]) & _native.SS_CSR_ERR_PROTOCOL:
+            mark_csr_protocol_faults_reported()
+            raise CsrProtocolFault('this CSR build gave up a cross-workgroup wait after its time bound: the adjacency is incomplete')
         if int(host[3]):
             raise IndexError(f'edge_index refers to nodes outside [0, {num_nodes})')
         csr.has_hub_rows = bool(int(host[2]) or int(host[4]))

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=../libsubgraph_sketch.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I ../../include $SS_EXTRA_FLAGS"
-UNITS="ss_init ss_csr ss_propagate ss_first_hop ss_fused_hop ss_count ss_pairs ss_heuristics ss_spmm ss_api ss_debug"
+UNITS="ss_init ss_digest ss_csr ss_propagate ss_first_hop ss_fused_hop ss_count ss_pairs ss_heuristics ss_spmm ss_api ss_debug"
 OBJS=""
 PIDS=""
 mkdir -p build

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int64_t *
         m = o > m ? o : m;
     }
     if (lane == 0 && m) atomicMax(&block_max, m);
-    if (bad && err) *err = 1;
+    if (bad && err) *err = 1;  // (SS_CSR_ERR_BOUNDS; a later wait_until that gives up adds bit 1 to it)
     if (bad && bad_record) *bad_record = 1;
     __syncthreads();
     if (threadIdx.x == 0) tile_max[blockIdx.x] = block_max;
@@ -686,6 +686,9 @@ struct RowOutputs {
     int hub_threshold;
     int32_t *hub_rows, *hub_count, *mega_rows, *mega_count;
     const int32_t *skip;  // see SS_CSR_SKIP
+    int32_t *err;         // the build's err_flag (nullable): bit 1 (SS_CSR_ERR_PROTOCOL) reports a wait that gave up, see wait_until
+    int32_t *fault_word;  // process-wide count of such waits in pinned host memory (nullable; ss_csr_protocol_faults reads it without synchronising)
+    unsigned long long wait_ticks;  // bound of wait_until
 };
 
 // exclusive scan of the per-node edge counts cnt[0..nb) of the bucket that starts at node0 -> excl[0..nb]; with `publish` the
@@ -762,20 +765,33 @@ constexpr int kSpentWord = 3;                                  // dense_count[3]
 constexpr unsigned long long kWaitTicks = 200000000ULL;        // wall_clock64 ticks (100 MHz): 2 s -- see wait_until
 constexpr unsigned long long kHelperPatienceTicks = 100000ULL;  // 1 ms: a dedicated helper that finds nothing for that long leaves
 
-// a wait that (by the rule above) only running workgroups can end; should that ever be wrong it gives up after ~2 s and counts a
-// fault (ss_debug_csr_protocol_faults: the tests assert 0) instead of hanging the device or trapping the context
+// a wait that (by the rule above) only running workgroups can end; should that ever be wrong (a process descheduled for seconds:
+// a debugger, heavy oversubscription) it gives up after ~2 s instead of hanging the device or trapping the context -- and the
+// build then FAILS LOUDLY: the share is not placed, so the CSR is incomplete, and the give-up is reported three ways --
+// bit 1 of the build's err_flag (SS_CSR_ERR_PROTOCOL: whoever reads the flag for out-of-range ids sees it), the process-wide
+// count in pinned host memory behind ss_csr_protocol_faults() (read without synchronising: the host mirror raises from its next
+// call / check_errors() even for builds that were given no flag, e.g. ss_group_links_by_source) and the device counter of the
+// tests (ss_debug_csr_protocol_faults)
 __device__ int csr_protocol_faults;
-__device__ __forceinline__ bool wait_until(int32_t *word, int target, int *flag)
+__device__ __forceinline__ bool wait_until(int32_t *word, int target, int *flag, int32_t *err, int32_t *fault_word, unsigned long long ticks)
 {
     if (threadIdx.x == 0) {
         const unsigned long long t0 = wall_clock64();
         int ok = 1;
         while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (wall_clock64() - t0 >= ticks) { ok = 0; break; }
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > kWaitTicks) { ok = 0; break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (!ok) atomicAdd(&csr_protocol_faults, 1);
+        if (!ok) {
+            atomicAdd(&csr_protocol_faults, 1);
+            // plain system-scope loads / stores, no read-modify-write on host memory (an atomic there needs PCIe AtomicOps end to end;
+            // racing reporters only have to leave SOMETHING non-zero behind)
+            if (err) __hip_atomic_store(err, __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) | SS_CSR_ERR_PROTOCOL, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_SYSTEM);
+            if (fault_word)  // a stamp that differs from the one before (the clock moves on), never 0
+                __hip_atomic_store(fault_word, (int32_t)((wall_clock64() >> 4) & 0x7FFFFFFF) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         *flag = ok;
     }
     __syncthreads();
@@ -1248,7 +1264,7 @@ __device__ __forceinline__ bool dense_help_bucket(DenseRunLds &lds, uint32_t *st
     if (mine < 0) return false;
     SS_MARK(11);
     // every share of the bucket is claimed (the counter ran out above), each by a workgroup that is inside its count step: safe to wait
-    if (!wait_until(&sy->counted, b.shares, &lds.flag)) return true;
+    if (!wait_until(&sy->counted, b.shares, &lds.flag, o.err, o.fault_word, o.wait_ticks)) return true;
     SS_MARK(12);
     // ---- place: the share whose records are still here ...
     {
@@ -1742,6 +1758,7 @@ extern "C" int ss_debug_csr_protocol_faults(void)
     return v;
 }
 
+
 #ifdef SS_CSR_TIMING
 extern "C" int ss_csr_timing_read(unsigned long long *out16, int reset)
 {
@@ -1780,6 +1797,36 @@ static int csr_check(const int64_t *src, const int64_t *dst, int64_t E, int64_t 
     return SS_OK;
 }
 
+// the process-wide fault count of wait_until: pinned + portable (every device of the process reaches it) + coherent host memory,
+// allocated on first use and never freed; nullptr if the allocation fails (then only err_flag and the debug counter report)
+static int32_t *protocol_fault_word()
+{
+    static int32_t *word = [] {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            return (int32_t *)nullptr;
+        }
+        memset(p, 0, 64);
+        return (int32_t *)p;
+    }();
+    return word;
+}
+// SS_CSR_WAIT_TICKS (100 MHz ticks; test hook: 0 makes every wait that is not already satisfied give up): the bound of wait_until
+static unsigned long long protocol_wait_ticks()
+{
+    static const unsigned long long ticks = getenv("SS_CSR_WAIT_TICKS") ? strtoull(getenv("SS_CSR_WAIT_TICKS"), nullptr, 10) : ss::kWaitTicks;
+    return ticks;
+}
+
+// (subgraph_sketch.h) what the product reads: one int32 in pinned, portable host memory that every finish launch of this process
+// stamps when a wait gives up -- read here with a plain load, no synchronisation, whatever the device
+extern "C" int ss_csr_protocol_faults(void)
+{
+    const int32_t *w = protocol_fault_word();
+    return w ? __atomic_load_n(w, __ATOMIC_RELAXED) : -1;
+}
+
 // the launches of one build (arguments checked by csr_check)
 static int csr_build_launch(const ss::LevelPlan &lp, const int64_t *src, const int64_t *dst, int64_t E, int64_t N, int64_t *rowptr, int32_t *col,
                             int64_t *n_self_loops_out, int32_t hub_threshold, int32_t *hub_rows, int32_t *hub_count, int32_t *mega_rows,
@@ -1795,7 +1842,7 @@ static int csr_build_launch(const ss::LevelPlan &lp, const int64_t *src, const i
         return SS_OK;
     }
     ProfileSpan span(stream, SS_PROF_CSR);  // all launches of this build
-    const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count, skip};
+    const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count, skip, err_flag, protocol_fault_word(), protocol_wait_ticks()};
     const Workspace w = carve(lp, E, workspace);
     unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
     const int tiles0 = (int)lp.tmax[0];

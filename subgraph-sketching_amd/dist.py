@@ -25,25 +25,204 @@ def shard_bounds(n_items, world_size, rank):
     return lo, min(lo + per, n_items)
 
 
-def sharded_subgraph_features(compute, links, group=None):
-    """every rank passes the SAME links [L, 2]; rank r computes `compute(links[lo:hi])` -> [hi-lo, F] and all
-    ranks return the full [L, F] tensor in the original order.
+class LinkRounds(object):
+    """which links of a set of L a rank computes when the rows are to be GATHERED, and where their rows lie.
 
-    compute: callable(links_shard) -> float tensor on the communication device (e.g.
-             lambda lk: eh.get_subgraph_features(lk, table, cards))"""
-    if not (dist.is_available() and dist.is_initialized()):
+    The set is cut into ROUNDS of `world * block` consecutive links; inside a round rank r owns the r-th block.  The rows of a round
+    are then one contiguous piece of the output IN THE CALLER'S ORDER with rank r's rows as its r-th equal part -- exactly the layout
+    `all_gather_into_tensor` produces, so every round is gathered IN PLACE into its final position (input = the owned block of the
+    output) as soon as its launches are queued, while the next round's launches run: no staging buffer, no padding copy, no
+    permutation afterwards.  The last, shorter round takes blocks of ceil(tail / world) links (its last blocks may be short or
+    empty; the output is allocated with the few padding rows that needs and returned without them).
+    (reference: get_subgraph_features is a map over rows, hashing.py:258-323; datasets/elph.py:200-213 computes every link of a
+    split in one call and keeps the rows in one tensor)"""
+
+    def __init__(self, n_links, world, rank, block):
+        if block < 1:
+            raise ValueError('block must be positive')
+        self.n_links, self.world, self.rank, self.block = n_links, world, rank, block
+        self.rounds = []  # (first link of the round, links per block)
+        span = world * block
+        full = n_links // span
+        self.rounds = [(c * span, block) for c in range(full)]
+        tail = n_links - full * span
+        if tail:
+            self.rounds.append((full * span, (tail + world - 1) // world))
+        self.padded_links = (self.rounds[-1][0] + world * self.rounds[-1][1]) if self.rounds else 0
+
+    def owned(self, c, rank=None):
+        """[lo, hi) of the links rank `rank` (default: this one) computes in round c -- hi - lo < links-per-block only in the last round"""
+        base, per = self.rounds[c]
+        r = self.rank if rank is None else rank
+        lo = min(base + r * per, self.n_links)
+        return lo, min(lo + per, self.n_links)
+
+    def owned_count(self, rank=None):
+        return sum(hi - lo for lo, hi in (self.owned(c, rank) for c in range(len(self.rounds))))
+
+    def owned_index(self, device=None, rank=None):
+        """int64 [owned_count]: the positions in the caller's link set of the rows this rank computes, round by round"""
+        parts = [torch.arange(lo, hi, dtype=torch.int64, device=device) for lo, hi in (self.owned(c, rank) for c in range(len(self.rounds)))]
+        return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=device)
+
+
+def default_link_block(n_links, world):
+    """links per block of LinkRounds when the caller names none: a QUARTER of a rank's share (three quarters of the gather then run
+    under later rounds' launches), at least 2^21 and at most 2^24 links.  Why not smaller: the query groups every block by first
+    node on its own (knobs.GROUP_LINKS_MIN), and a block holds a source far fewer times than the share does -- measured on one
+    rank's share of a BUDDY link set at 8 ranks, random pairs (tools/probe_link_blocks.py, profiles/round6_link_blocks.txt):
+    ogbl-citation2 size (44.5 M links) whole share 29.9 ms, blocks of 11 M 32.3, 5.6 M 35.8, 1 M 46.7; ogbl-ppa size (7.2 M) 2.75 /
+    4 M 2.82 / 2 M 3.13 / 1 M 3.62 ms.  Lists that already have their runs (ogbl-citation2's evaluation sets: 1 000 negatives per
+    source, listed together) lose 1-2 % at any of these sizes."""
+    share = (n_links + world - 1) // max(world, 1)
+    return int(min(max((share + 3) // 4, 1 << 21), 1 << 24))
+
+
+class ShardedFeatures(object):
+    """what sharded_precompute returns.  rows: the [L, F] tensor in the caller's order where the gather mode puts it (every rank /
+    group rank 0 / nowhere), else None; local: this rank's own rows [owned, F] (`index[i]` = position of row i in the caller's
+    link set) -- what a data-parallel training loop that keeps its shard of the links reads (runners/train.py:58-60 indexes the
+    feature tensor per batch); for a rank that holds `rows`, `local` is gathered from it on first use."""
+
+    def __init__(self, rows, local, index_fn):
+        self.rows, self._local, self._index_fn, self._index = rows, local, index_fn, None
+
+    @property
+    def index(self):
+        if self._index is None:
+            self._index = self._index_fn()
+        return self._index
+
+    @property
+    def local(self):
+        if self._local is None and self.rows is not None:
+            self._local = self.rows[self.index.to(self.rows.device)]
+        return self._local
+
+
+GATHER_MODES = ('all', 'rank0', 'none')
+
+
+def _sharded_rows(fill, links, width, device, group, gather, block, dtype=torch.float32):
+    """the machinery of sharded_precompute / sharded_subgraph_features.  fill(link_slice, out_view): compute the rows of the
+    slice into out_view ([len, width], contiguous, on `device`; launches are queued on the current stream, nothing waits)."""
+    if gather not in GATHER_MODES:
+        raise ValueError(f'gather must be one of {GATHER_MODES}, got {gather!r}')
+    L = links.size(0)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if gather == 'none':
+        # nothing is exchanged: a contiguous share per rank -- the query then groups the WHOLE share by first node at once (every
+        # repeat of a source inside the share is found, not only those inside a block)
+        lo, hi = shard_bounds(L, world, rank)
+        local = torch.empty((hi - lo, width), dtype=dtype, device=device)
+        fill(links[lo:hi], local)
+        return ShardedFeatures(None, local, lambda: torch.arange(lo, hi, dtype=torch.int64, device=device))
+    plan = LinkRounds(L, world, rank, block or default_link_block(L, world))
+    native = dist.get_backend(group) == 'nccl'
+    on_device = torch.device(device).type == 'cuda'
+    holds_all = gather == 'all' or rank == 0
+    # ranks that end up with every row compute theirs straight into the final tensor; the others (gather = 'rank0') into a
+    # buffer of their own rows only
+    full = torch.empty((plan.padded_links, width), dtype=dtype, device=device) if holds_all else None
+    own = None if holds_all else torch.empty((plan.owned_count() + (plan.rounds[-1][1] if plan.rounds else 0), width), dtype=dtype, device=device)
+    root = 0 if group is None else dist.get_global_rank(group, 0)
+    works, own_at = [], 0
+    for c, (base, per) in enumerate(plan.rounds):
+        lo, hi = plan.owned(c)
+        if holds_all:
+            block_view = full[base + rank * per:base + (rank + 1) * per]
+        else:
+            block_view = own[own_at:own_at + per]
+            own_at += hi - lo
+        if hi > lo:
+            fill(links[lo:hi], block_view[:hi - lo])
+        piece = full[base:base + world * per] if holds_all else None
+        # the round's exchange, issued at once: over RCCL it runs on RCCL's stream behind THIS round's launches (the collective
+        # waits for what the current stream holds at this point) and under the next rounds' -- the host does not block
+        if gather == 'all':
+            if native or not on_device:
+                w = dist.all_gather_into_tensor(piece, block_view if native else block_view.clone(), group=group, async_op=native)
+                if native:
+                    works.append(w)
+            else:  # device tensors on a backend without device collectives (gloo in the one-GPU tests): through the host
+                staged = torch.empty(piece.shape, dtype=dtype, device='cpu')
+                dist.all_gather_into_tensor(staged, block_view.cpu(), group=group)
+                piece.copy_(staged)
+        else:  # 'rank0'
+            if native or not on_device:
+                dests = [piece[q * per:(q + 1) * per] for q in range(world)] if rank == 0 else None
+                w = dist.gather(block_view if native else block_view.clone(), dests, dst=root, group=group, async_op=native)
+                if native:
+                    works.append(w)
+            else:
+                dests = [torch.empty((per, width), dtype=dtype, device='cpu') for _ in range(world)] if rank == 0 else None
+                dist.gather(block_view.cpu(), dests, dst=root, group=group)
+                if rank == 0:
+                    piece.copy_(torch.cat(dests, dim=0))
+    for w in works:
+        w.wait()  # the current stream waits for the collectives; the host does not block
+    rows = full[:L] if holds_all else None
+    local = None if holds_all else own[:plan.owned_count()]
+    return ShardedFeatures(rows, local, lambda: plan.owned_index(device))
+
+
+def sharded_precompute(eh, links, hash_table, cards, group=None, gather='all', block=None, batch_size=11000000, degrees=None):
+    """BUDDY's feature precompute (reference datasets/elph.py:200-213: `get_subgraph_features(links, hashes, cards, batch_size)` over
+    every link of a split) across the ranks of `group`: every rank passes the SAME links and holds the same (replicated) tables.
+
+    gather: who ends up with the rows --
+      'none'  nobody exchanges anything: rank r computes a contiguous share and keeps it (`.local`, `.index`).  What a data-parallel
+              training loop needs (each rank trains on its shard of the links); the only mode whose cost is compute / world.
+      'all'   every rank ends with the full [L, F] tensor in the caller's order (`.rows`) -- the reference's single-process
+              semantics.  (world - 1) / world of L * F * 4 bytes arrive at every rank (ogbl-citation2: 18.7 of 21.4 GB), so the
+              exchange is NOT one collective after the job: the link set is walked in rounds (LinkRounds), each round's rows are
+              all-gathered in place while the next round's launches run.
+      'rank0' only group rank 0 ends with the tensor (the rank that writes the feature cache, datasets/elph.py:212-213); the same
+              bytes arrive there, the other ranks receive nothing.
+    block: links per rank and round (default_link_block).  Rows are bit-identical to the unsharded call (a pair's features depend
+    on its own sketch rows only).  Returns a ShardedFeatures."""
+    if links.dim() == 1:
+        links = links.unsqueeze(0)
+    nf = eh.max_hops * (eh.max_hops + 2)
+    width = 2 * nf if degrees is not None else nf
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        rows = eh.get_subgraph_features(links, hash_table, cards, batch_size=batch_size, degrees=degrees)
+        n = links.size(0)
+        return ShardedFeatures(rows if gather != 'none' else None, rows, lambda: torch.arange(n, dtype=torch.int64, device=rows.device))
+    from ._runtime import _compute_device
+    first = hash_table.get(1) if hasattr(hash_table, 'get') else None
+    device = _compute_device(links, getattr(first, 'mh_u32', None), cards)
+    lk = links.to(device=device, dtype=torch.int64).contiguous()
+
+    def fill(link_slice, out_view):
+        eh.get_subgraph_features(link_slice, hash_table, cards, batch_size=batch_size, degrees=degrees, out=out_view)
+    return _sharded_rows(fill, lk, width, device, group, gather, block)
+
+
+def sharded_subgraph_features(compute, links, group=None, gather='all', block=None):
+    """the same sharding around ANY row function: every rank passes the SAME links [L, 2]; `compute(link_slice) -> [len, F]` is
+    called for the slices this rank owns.  gather = 'all' (default): every rank returns the full [L, F] tensor in the original
+    order; 'rank0': group rank 0 does, the others return None; 'none': every rank returns its own contiguous share
+    (links[shard_bounds(L, world, rank)]).  See sharded_precompute for the engine's own form (rows stored in place)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1 or links.size(0) == 0:
         return compute(links)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     L = links.size(0)
-    lo, hi = shard_bounds(L, world, rank)
-    local = compute(links[lo:hi])
-    per = (L + world - 1) // world
-    F = local.size(1)
-    padded = local.new_zeros((per, F))
-    padded[:hi - lo] = local
-    gathered = local.new_empty((world * per, F))
-    _all_gather_rows(gathered, padded.contiguous(), group)
-    return gathered[:L]
+    block = block or max((L + world - 1) // world, 1)  # (one round: the contiguous shares of rounds 1-5, one compute call per rank)
+    # width / dtype / device of the rows are only known from a result: every rank computes the first slice it owns (a rank that
+    # owns none learns them from the others)
+    lo, hi = shard_bounds(L, world, rank) if gather == 'none' else LinkRounds(L, world, rank, block).owned(0)
+    first = compute(links[lo:hi]) if hi > lo else None
+    seen = [None] * world
+    dist.all_gather_object(seen, None if first is None else (first.size(1), first.dtype, str(first.device)), group=group)
+    width, dtype, device = next(x for x in seen if x is not None)
+    state = {'first': first}
+
+    def fill(link_slice, out_view):
+        cached, state['first'] = state['first'], None
+        out_view.copy_(cached if cached is not None else compute(link_slice))
+    res = _sharded_rows(fill, links, width, torch.device(device) if first is None else first.device, group, gather, block, dtype=dtype)
+    return res.local if gather == 'none' else res.rows
 
 
 def _all_gather_rows(dst, src, group=None, async_op=False):
@@ -211,7 +390,12 @@ class PeerShard(RowShard):
         # test_sharded_build_two_ranks_one_gpu[8] of rounds 3-4; no kernel of the library is involved.  Not recycling is the cure
         # that is ours to apply; what still fails is retried as a whole on fresh memory and, failing that, raised on every rank
         # (fallback=True of peer_write_build_hash_tables then takes the exchange form).
-        key = (id(group), self._carve.bytes, str(self.device))
+        # keyed on the LAYOUT, not only on the slab size: a pooled entry caches the peers' views carved with the creating shard's layout
+        # (two shapes of equal bytes would aim the mirrors at the old offsets: ADVICE r5); the group object is pinned by the pool so
+        # that its id cannot be handed to another group after a destroy / re-init
+        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        _POOL_GROUPS[id(pg)] = pg
+        key = (id(pg), rows, max_hops, num_perm, m, str(self.device))
         entry, errors = None, []
         for attempt in range(3):
             try:
@@ -234,8 +418,14 @@ class PeerShard(RowShard):
         import weakref
         # (the finaliser runs BEFORE the shard's own attributes are cleared: its views of the slab are still alive then, so "no tensor
         # of a build is left" means "the storage has as many users as right now")
-        weakref.finalize(self, _release_entry, key, entry, _storage_users(self._slab))  # the slab and its mappings outlive the shard
+        try:
+            users = _storage_users(self._slab)
+        except Exception as exc:  # noqa: BLE001  (a torch without the private hook: the constructor fails the way fallback=True expects)
+            _QUARANTINE.append(entry)
+            raise RuntimeError(f'peer-write build unavailable: cannot count the users of a slab ({exc!r})')
+        weakref.finalize(self, _release_entry, key, entry, users)  # the slab and its mappings outlive the shard
         self.generation = 0
+        self.verified, self.digests, self.failed = False, None, None  # (peer_write_build_hash_tables: replicas compared after the first build)
         self.hop_barrier()  # nobody starts storing into a table before everybody has mapped (and probed) it
 
     def _pooled_or_new(self, key, max_hops):
@@ -243,6 +433,15 @@ class PeerShard(RowShard):
         ALL ranks hold the same one free, else a new one (allocate, export, exchange, map) -- probed before it is returned.
         Raises RuntimeError on every rank or on none."""
         free = _POOL.setdefault(key, [])
+        # slabs set aside because a caller still held a table of theirs come back once that table is gone
+        for q in [q for q in _QUARANTINE if q.get('key') == key and not q.get('bad') and 'idle_users' in q]:
+            try:
+                idle = _storage_users(q['slab']) <= q['idle_users']
+            except Exception:  # noqa: BLE001
+                idle = False
+            if idle:
+                _QUARANTINE.remove(q)
+                free.append(q)
         everyone = [None] * self.world
         dist.all_gather_object(everyone, sorted(e['id'] for e in free), group=self.group)
         common = set(everyone[0]).intersection(*map(set, everyone[1:]))
@@ -267,9 +466,12 @@ class PeerShard(RowShard):
             mine = _export_tables([slab])
         except Exception as exc:  # noqa: BLE001
             failure = RuntimeError(f'IPC export failed: {type(exc).__name__}: {str(exc).splitlines()[0]} [{_fd_state()}; {_ipc_probe()}]')
-            if slab is not None:
-                _QUARANTINE.append({'slab': slab})
-        self._agree(failure, 'a rank could not export its tables')
+        try:
+            self._agree(failure, 'a rank could not export its tables')
+        except RuntimeError:
+            if slab is not None:  # on EVERY rank: memory that was (or may have been) exported is never handed back to the allocator
+                _QUARANTINE.append({'slab': slab, 'bad': True})
+            raise
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=self.group)
         peers, failure = {}, None
@@ -289,10 +491,18 @@ class PeerShard(RowShard):
                 peers[r] = (peer_slab, pm + ph + [pc])
         except Exception as exc:  # (mapping a peer's memory can fail on ONE rank only: agree before anybody waits for anybody)
             failure = exc
-            _QUARANTINE.append({'slab': slab, 'peers': peers})
-        self._agree(failure, 'a rank could not map its peers\' tables')
+        try:
+            self._agree(failure, 'a rank could not map its peers\' tables')
+        except RuntimeError:
+            _QUARANTINE.append({'slab': slab, 'peers': peers, 'bad': True})  # (the ranks that did map keep their slab out of the allocator too)
+            raise
         _POOL_IDS[key] = _POOL_IDS.get(key, 0) + 1  # (creations are collective: the counter agrees across ranks)
-        return {'id': _POOL_IDS[key], 'slab': slab, 'peers': peers}
+        entry = {'id': _POOL_IDS[key], 'slab': slab, 'peers': peers, 'key': key}
+        try:
+            entry['idle_users'] = _storage_users(slab)  # (the slab with nobody's views on it: what "no table of a build is left" looks like)
+        except Exception:  # noqa: BLE001
+            pass
+        return entry
 
     def _probe(self, entry, max_hops):
         """store-and-read-back through every mirror: rank r writes a fresh token into row r of every PEER's cards table (column 0), a
@@ -360,7 +570,8 @@ class PeerShard(RowShard):
             dist.barrier(group=self.group)
 
 
-_POOL = {}        # (group, slab bytes, device) -> free pool entries (see PeerShard.__init__)
+_POOL = {}        # (group, rows, hops, permutations, registers, device) -> free pool entries (see PeerShard.__init__)
+_POOL_GROUPS = {}  # id(process group) -> the group object (pinned: a destroyed group's id must not be reused by another one)
 _POOL_IDS = {}    # same key -> entries created so far
 _QUARANTINE = []  # slabs / mappings of constructions that failed: never reused, never freed (their memory must not be recycled)
 
@@ -442,6 +653,58 @@ def _enable_peer_access(device, other):
     torch.cuda.synchronize(device)
 
 
+class ReplicaMismatch(RuntimeError):
+    """the sketch tables of the ranks of a group differ after a build that must leave identical replicas"""
+
+
+def table_digests(tensors):
+    """int64 [len(tensors), 2]: ss_table_digest (128-bit content digest, one streaming pass) of every tensor (contiguous, on one device)"""
+    from . import _native
+    from ._runtime import _ptr, _stream
+    lib = _native.lib()
+    device = tensors[0].device
+    out = torch.empty((len(tensors), 2), dtype=torch.int64, device=device)
+    for i, t in enumerate(tensors):
+        if not t.is_contiguous():
+            raise ValueError('table_digests needs contiguous tensors')
+        nbytes = t.numel() * t.element_size()
+        if nbytes % 16:  # (cards [N, h] with N * h odd: digest a zero-padded copy -- the same on every rank)
+            padded = torch.zeros((nbytes + 15) // 16 * 16, dtype=torch.uint8, device=device)
+            padded[:nbytes] = t.reshape(-1).view(torch.uint8)
+            t, nbytes = padded, padded.numel()
+        _native.check(lib.ss_table_digest(_ptr(t), nbytes, _ptr(out[i]), _stream(device)), 'ss_table_digest')
+    return out
+
+
+def verify_replicas(table, cards, max_hops, num_nodes, group=None, what='build'):
+    """every rank digests its hop 1 .. max_hops MinHash / HLL tables and its cards (rows [0, num_nodes)) on the device, the digests
+    are exchanged, and EVERY rank raises ReplicaMismatch if any two replicas differ -- or returns the digests.  One streaming read
+    of the tables (ogbl-ppa size: 0.9 GB, ~0.15 ms) plus one small host-side exchange; the reference has one table
+    (hashing.py:139-165), a multi-GPU build must leave the same one everywhere."""
+    tensors = []
+    for k in range(1, max_hops + 1):
+        tensors += [table[k].mh_u32[:num_nodes], table[k].hll_u8[:num_nodes]]
+    tensors.append(cards[:num_nodes].contiguous())
+    mine = table_digests(tensors).cpu().tolist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine, group=group)
+    names = [f'hop {k} {kind}' for k in range(1, max_hops + 1) for kind in ('minhash', 'hll')] + ['cards']
+    bad = sorted({names[i] for r in range(1, world) for i in range(len(names)) if everyone[r][i] != everyone[0][i]})
+    if bad:
+        differing = sorted({r for r in range(1, world) for i in range(len(names)) if everyone[r][i] != everyone[0][i]})
+        raise ReplicaMismatch(f'{what}: the replicas of {bad} differ between group rank 0 and rank(s) {differing} (this is rank {rank}): '
+                              f'rows written by one GPU were not (all) seen by another')
+    return mine
+
+
+def _peer_verify_mode():
+    mode = os.environ.get('SS_PEER_VERIFY', 'first')
+    if mode not in ('first', 'always', 'never'):
+        raise ValueError(f'SS_PEER_VERIFY must be first, always or never, got {mode!r}')
+    return mode
+
+
 def peer_write_build_hash_tables(eh, num_nodes, edge_index, shard=None, group=None, fallback=False):
     """`eh.build_hash_tables` with the rows of every hop computed once across the group and written straight into every rank's
     tables (PeerShard).  Pass the shard of an earlier call to reuse its IPC-shared buffers (the tables of that earlier build are
@@ -461,6 +724,23 @@ def peer_write_build_hash_tables(eh, num_nodes, edge_index, shard=None, group=No
             table, cards = sharded_build_hash_tables(eh, num_nodes, edge_index, group)
             return table, cards, None
     table, cards = eh._build(num_nodes, edge_index, shard)
+    # PeerShard's constructor has probed every mapping with ONE store; what a build relies on is that EVERY row its peers' kernels stored
+    # is visible to this rank's next kernel after the hop barrier (coarse-grained device memory written from another GPU, lines of
+    # the previous build possibly still in this GPU's L2).  Checked, not assumed: after the FIRST build through a shard (SS_PEER_VERIFY =
+    # first, the default; always: every build; never) the replicas' digests are compared; a mismatch raises on every rank -- or, with
+    # fallback=True, rebuilds through the exchange form and retires the shard.
+    mode = _peer_verify_mode()
+    if mode == 'always' or (mode == 'first' and not shard.verified):
+        try:
+            shard.digests = verify_replicas(table, cards, eh.max_hops, num_nodes, group, 'peer-write build')
+            shard.verified = True
+        except ReplicaMismatch as exc:
+            shard.failed = str(exc)
+            logger.error('%s', exc)
+            if not fallback:
+                raise
+            table, cards = sharded_build_hash_tables(eh, num_nodes, edge_index, group)
+            return table, cards, None
     return table, cards, shard
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _native, hll_tables, knobs
-from ._runtime import (_DeferredErrors, _DeviceParams, _Span, _check_sizes, _compute_device, _error_flag, _ptr, _stream, _take_error,
+from ._runtime import (CsrProtocolFault, raise_csr_protocol_faults, _DeferredErrors, _DeviceParams, _Span, _check_sizes, _compute_device, _error_flag, _ptr, _stream, _take_error,
                        linear_counting_table, logger)
 from .containers import (HopSketch, LazyMinhash, SketchTable, _packed_hll_of, _packed_minhash_of, _stamp_tables, _tag, unpack_minhash)
 from .csr import _CsrCache, build_csr, group_links_by_source
@@ -196,6 +196,7 @@ class ElphHashes(object):
         if self.strict_bounds == 'deferred':
             self._deferred.raise_if_set()
             return False, self._deferred.flag(device, what)
+        raise_csr_protocol_faults()  # (strict / unchecked modes pass no deferred word: the library's own count still reports)
         return bool(self.strict_bounds), None
 
     def _prop_hub_hint(self, device, num_nodes, edge_index):
@@ -387,10 +388,11 @@ class ElphHashes(object):
                 raise ValueError('hash tables of different hops must have the same shape')
         return mh, hll, N, P
 
-    def _pair_kernel(self, links, hash_table, cards, want_debug=False, degrees=None, floor_sf=None, group_batch=None):
+    def _pair_kernel(self, links, hash_table, cards, want_debug=False, degrees=None, floor_sf=None, group_batch=None, out=None):
         """runs ss_pair_features for links [B,2]; returns (features [B,nf] (or [B,2nf] with degrees) on device, debug dict or None).
         group_batch: the links are first grouped by their first node and walked in that order, `group_batch` pairs per launch
-        (knobs.GROUP_LINKS_MIN; same rows, in the caller's order)"""
+        (knobs.GROUP_LINKS_MIN; same rows, in the caller's order).  out: the rows are written THERE (a contiguous float32
+        [B, width] tensor on the compute device -- a slice of a larger result, dist.sharded_precompute) instead of a fresh tensor"""
         # where the links live, else where the packed tables already are, else cards, else the current device
         first = hash_table.get(1) if hasattr(hash_table, 'get') else None
         device = _compute_device(links, first.mh_u32 if isinstance(first, HopSketch) else None, cards)
@@ -421,6 +423,9 @@ class ElphHashes(object):
             if cd.stride(1) != 1:
                 cd = cd.contiguous()
         nf = h * (h + 2)
+        width = 2 * nf if degrees is not None else nf
+        if out is not None and (out.device != device or out.dtype != torch.float32 or tuple(out.shape) != (B, width) or not out.is_contiguous()):
+            raise ValueError(f'out must be a contiguous float32 [{B}, {width}] tensor on {device}, got {out.dtype} {tuple(out.shape)} on {out.device}')
         mh_ptrs = (c_void_p * h)(*[t.data_ptr() for t in mh])
         hll_ptrs = (c_void_p * h)(*[t.data_ptr() for t in hll])
         floor = self.floor_sf if floor_sf is None else floor_sf  # DeviceFeatureStore records HashDataset's post-hoc floor
@@ -441,8 +446,9 @@ class ElphHashes(object):
             if mode == 'auto':
                 mode = float((lk[1:, 0] == lk[:-1, 0]).sum().item()) < 0.5 * (B - 1)
             order = group_links_by_source(lk, N, device) if mode else None
-            nf_out = 2 * nf if dg is not None else nf
-            out = torch.empty((B, nf_out), dtype=torch.float32, device=device)
+            nf_out = width
+            if out is None:
+                out = torch.empty((B, nf_out), dtype=torch.float32, device=device)
             for s0 in range(0, B, group_batch):
                 nb = min(group_batch, B - s0)
                 lib = _native.lib()
@@ -469,7 +475,8 @@ class ElphHashes(object):
                 raise IndexError(f'links refer to nodes outside [-{N}, {N})')
             return out, None
         if degrees is not None:
-            out = torch.empty((B, 2 * nf), dtype=torch.float32, device=device)
+            if out is None:
+                out = torch.empty((B, 2 * nf), dtype=torch.float32, device=device)
             with _Span('pair_features', device):
                 _native.check(_native.lib().ss_pair_features_normalised(
                     _ptr(lk), B, N, h, mh_ptrs, P, hll_ptrs, _ptr(cd), cd.stride(0), byref(params.struct), flags, _ptr(dg),
@@ -477,7 +484,8 @@ class ElphHashes(object):
             if strict and B > 0 and _take_error(device):
                 raise IndexError(f'links refer to nodes outside [-{N}, {N})')
             return out, None
-        out = torch.empty((B, nf), dtype=torch.float32, device=device)
+        if out is None:
+            out = torch.empty((B, nf), dtype=torch.float32, device=device)
         dbg = None
         if want_debug:
             dbg = {'match': torch.empty((B, h, h), dtype=torch.int32, device=device),
@@ -564,7 +572,7 @@ class ElphHashes(object):
             raise ValueError('source and destination hash value shapes must be the same')
         return torch.count_nonzero(src == dst, dim=-1) / self.num_perm
 
-    def get_subgraph_features(self, links, hash_table, cards, batch_size=11000000, degrees=None, lazy=False):
+    def get_subgraph_features(self, links, hash_table, cards, batch_size=11000000, degrees=None, lazy=False, out=None):
         """structural features of node pairs: approximations of the number of nodes at distance (d_u, d_v)
         from (u, v), for the (d_u, d_v) listed in LABEL_LOOKUP[max_hops] (reference :258-323).
         @param links: int tensor [n_edges, 2] (or [2])
@@ -576,6 +584,9 @@ class ElphHashes(object):
                sqrt(d_u * d_v), NaN / Inf -> 0) is appended in the same kernel and the result is [n_edges, 2 * F].
         @param lazy: extension: return a `DeviceFeatureStore` (feature_store.py) instead of the tensor -- rows are computed on
                the GPU when a batch indexes it (runners/train.py:58-60), nothing of size [n_edges, F] is materialised
+        @param out: extension: a contiguous float32 [n_edges, F] tensor ON THE COMPUTE DEVICE the rows are written into (and which
+               is returned): a slice of a larger result -- dist.sharded_precompute lets every launch store straight into the block
+               of the output the collective then sends from
         @return: float32 [n_edges, max_hops * (max_hops + 2)] on links.device"""
         if self.max_hops not in (1, 2, 3):
             raise NotImplementedError("Only 1, 2 and 3 hop hashes are implemented")
@@ -586,14 +597,18 @@ class ElphHashes(object):
             return DeviceFeatureStore(self, links, hash_table, cards, degrees=degrees, batch_size=batch_size)
         n = links.size(0)
         if knobs.GROUP_LINKS_MIN and n >= knobs.GROUP_LINKS_MIN and n < (1 << 31):
-            feats, _ = self._pair_kernel(links, hash_table, cards, degrees=degrees, group_batch=max(int(batch_size), 1))
+            feats, _ = self._pair_kernel(links, hash_table, cards, degrees=degrees, group_batch=max(int(batch_size), 1), out=out)
         elif n <= batch_size:
-            feats, _ = self._pair_kernel(links, hash_table, cards, degrees=degrees)
+            feats, _ = self._pair_kernel(links, hash_table, cards, degrees=degrees, out=out)
+        elif out is not None:
+            for s in range(0, n, batch_size):
+                self._pair_kernel(links[s:s + batch_size], hash_table, cards, degrees=degrees, out=out[s:s + batch_size])
+            feats = out
         else:
             chunks = [self._pair_kernel(links[s:s + batch_size], hash_table, cards, degrees=degrees)[0]
                       for s in range(0, n, batch_size)]
             feats = torch.cat(chunks, dim=0)
-        if feats.device == links.device:
+        if feats.device == links.device or out is not None:
             return feats
         out = feats.to(links.device)
         # links on another device (BUDDY keeps them on the CPU): the copy back has waited for the launches, so the deferred

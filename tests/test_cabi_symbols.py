@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_strings():
     import subgraph_sketching_amd as ssa
     lib = ssa._native.lib()
-    assert lib.ss_version() == 128 == ssa._native.ABI_VERSION
+    assert lib.ss_version() == 129 == ssa._native.ABI_VERSION
     assert lib.ss_error_string(0) == b'ok'
     assert b'invalid' in lib.ss_error_string(-1)
     assert lib.ss_csr_workspace_bytes(1000, 5000) >= 8 * 1001

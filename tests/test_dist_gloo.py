@@ -42,7 +42,7 @@ def _worker(rank, world, port, L, out_dir):
 
     full = ssa.dist.sharded_subgraph_features(compute, links)
     lo, hi = ssa.dist.shard_bounds(L, world, rank)
-    assert calls == [hi - lo]
+    assert calls == ([hi - lo] if hi > lo else [])  # default: one round = the contiguous shares, one compute call per rank
     ref = torch.from_numpy(oracle.pair_features(links.numpy(), tables, cards, 2, prm)) if L else torch.zeros((0, 8))
     assert full.shape == (L, 8) and torch.equal(full, ref), f'rank {rank}: gathered features differ'
     torch.save(full, os.path.join(out_dir, f'rank{rank}.pt'))
@@ -55,6 +55,85 @@ def test_sharded_query_world2(tmp_path, L):
     mp.spawn(_worker, args=(world, _free_port(), L, str(tmp_path)), nprocs=world, join=True)
     a, b = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
     assert torch.equal(a, b)  # every rank ends with the same, complete, ordered result
+
+
+# ---- the BUDDY precompute across ranks: rounds of blocks gathered in place, three gather modes -------------------
+def test_link_rounds_partition():
+    """LinkRounds: every link is owned by exactly one rank; a round's rows are one contiguous piece with rank r's block as its r-th
+    equal part (the layout all_gather_into_tensor writes); the padding stays below one block per rank"""
+    import subgraph_sketching_amd as ssa
+    for L in (0, 1, 7, 1001, 65536):
+        for world in (1, 2, 3, 8):
+            for block in (1, 5, 300, 10 ** 6):
+                if L // (world * block) > 5000:
+                    continue
+                plans = [ssa.dist.LinkRounds(L, world, r, block) for r in range(world)]
+                owner = np.full(L, -1)
+                for r, plan in enumerate(plans):
+                    assert plan.rounds == plans[0].rounds and plan.padded_links == plans[0].padded_links
+                    for c, (base, per) in enumerate(plan.rounds):
+                        lo, hi = plan.owned(c)
+                        assert 0 <= hi - lo <= per and (lo == hi or lo == base + r * per)
+                        assert (owner[lo:hi] == -1).all()
+                        owner[lo:hi] = r
+                    idx = plan.owned_index()
+                    assert idx.numel() == plan.owned_count() and (owner[idx.numpy()] == r).all()
+                assert (owner >= 0).all() and L <= plans[0].padded_links < L + world * min(block, max(L, 1)) + 1
+                for (base, per), nxt in zip(plans[0].rounds, plans[0].rounds[1:] + [(plans[0].padded_links, 0)]):
+                    assert base + world * per == nxt[0]  # rounds tile the (padded) output
+    assert ssa.dist.default_link_block(356_000_000, 8) == 11_125_000 and ssa.dist.default_link_block(65536, 8) == 1 << 21
+    with pytest.raises(ValueError):
+        ssa.dist.LinkRounds(10, 2, 0, 0)
+
+
+def _rounds_worker(rank, world, port, L, block, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import subgraph_sketching_amd as ssa
+    F = 15
+    links = torch.from_numpy(np.random.RandomState(4).randint(0, 1000, size=(L, 2)).astype(np.int64))
+    rows_of = lambda lk: (lk[:, :1] * 1000 + lk[:, 1:]).float() + torch.arange(F, dtype=torch.float32)[None, :]
+    ref = rows_of(links)
+    for gather in ssa.dist.GATHER_MODES:
+        calls = []
+
+        def fill(link_slice, out_view):
+            calls.append(link_slice.size(0))
+            assert out_view.shape == (link_slice.size(0), F) and out_view.is_contiguous()
+            out_view.copy_(rows_of(link_slice))
+        res = ssa.dist._sharded_rows(fill, links, F, torch.device('cpu'), None, gather, block)
+        if gather == 'none':
+            lo, hi = ssa.dist.shard_bounds(L, world, rank)
+            assert res.rows is None and calls == [hi - lo] and torch.equal(res.index, torch.arange(lo, hi))
+        else:
+            plan = ssa.dist.LinkRounds(L, world, rank, block)
+            assert calls == [hi - lo for lo, hi in (plan.owned(c) for c in range(len(plan.rounds))) if hi > lo]
+            if gather == 'all' or rank == 0:
+                assert res.rows.shape == (L, F) and torch.equal(res.rows, ref), f'rank {rank} {gather}: gathered rows differ'
+            else:
+                assert res.rows is None
+        assert torch.equal(res.local, ref[res.index]), f'rank {rank} {gather}: local rows differ'
+        # the callable form returns the tensor of the mode
+        got = ssa.dist.sharded_subgraph_features(rows_of, links, gather=gather, block=block)
+        if gather == 'none':
+            lo, hi = ssa.dist.shard_bounds(L, world, rank)
+            assert torch.equal(got, ref[lo:hi])
+        elif gather == 'all' or rank == 0:
+            assert torch.equal(got, ref)
+        else:
+            assert got is None
+    owned = [None] * world
+    dist.all_gather_object(owned, res.index.tolist())
+    assert sorted(i for part in owned for i in part) == list(range(L))  # the shares of the ranks partition the link set
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,L,block', [(2, 1001, 100), (3, 1000, 64), (2, 5, 100), (3, 2, 1), (2, 600, 300)])
+def test_precompute_rounds_and_gather_modes(tmp_path, world, L, block):
+    """sharded_precompute's machinery on gloo: several rounds + a ragged tail, gather = all / rank0 / none"""
+    mp.spawn(_rounds_worker, args=(world, _free_port(), L, block, str(tmp_path)), nprocs=world, join=True)
 
 
 # ---- sharded build (SURVEY 8(e)): destination rows partitioned, in-place all-gather after every hop ------------------
