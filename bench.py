@@ -196,8 +196,7 @@ def emit(out):
 
 def resident_label(rf, table_bytes):
     """where the gathered table lives, from the share of it the 256 MiB Infinity Cache can hold: all of it / most of it / little of it"""
-    f = rf.cache_resident_fraction(table_bytes)
-    return 'infinity-cache' if f >= 1.0 else ('mixed' if f >= 0.5 else 'hbm')
+    return rf.resident_label(table_bytes)
 
 
 # the rows above the hub threshold are walked as hub units by leading workgroups of the row launches (csrc/ss_hub.hpp); SS_HUB_LAUNCHES=1
@@ -398,6 +397,12 @@ def configs_3_4_strong(ssa, dist, dev, world, rank, reps=2, with_peer=False, lin
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()) * 1e3
 
+    t_start = time.perf_counter()
+
+    def progress(msg):  # (stderr, rank 0: where a run that is cut short by the watchdog got to)
+        if rank == 0 and os.environ.get('SS_BENCH_VERBOSE', '1') != '0':
+            print(f'[configs_3_4_strong +{time.perf_counter() - t_start:6.1f} s] {msg}', file=sys.stderr, flush=True)
+
     for name in ('ppa', 'citation2'):
         if only and name not in only:
             continue
@@ -416,13 +421,17 @@ def configs_3_4_strong(ssa, dist, dev, world, rank, reps=2, with_peer=False, lin
         def one_gpu():
             table, cards = eh.build_hash_tables(n, ei)
             return eh.get_subgraph_features(links, table, cards)
+        progress(f'{name}: graph + {L} links on the device')
         row['ms_1gpu_same_work'] = timed(one_gpu)
         row['pairs_per_s_1gpu'] = L / (row['ms_1gpu_same_work'] * 1e-3)
+        progress(f'{name}: one GPU {row["ms_1gpu_same_work"]:.2f} ms')
         builds = [('replicated_build', lambda: eh.build_hash_tables(n, ei)), ('sharded_build', lambda: ssa.dist.sharded_build_hash_tables(eh, n, ei))]
         shard_box = {}
         if with_peer:
             try:
+                progress(f'{name}: mapping the peers\' tables (PeerShard)')
                 shard_box['s'] = ssa.dist.PeerShard(n, eh.max_hops, eh.num_perm, eh.m, dev)
+                progress(f'{name}: mapped')
                 builds.append(('peer_write_build', lambda: ssa.dist.peer_write_build_hash_tables(eh, n, ei, shard=shard_box['s'])[:2]))
             except Exception as exc:
                 row['peer_write_build_unavailable'] = f'{type(exc).__name__}: {str(exc)[:200]}'
@@ -436,6 +445,7 @@ def configs_3_4_strong(ssa, dist, dev, world, rank, reps=2, with_peer=False, lin
                     tn = timed(job)
                     row['variants'][f'{bname}+gather_{gather}'] = {'ms': tn, 'speedup_vs_1gpu_same_work': row['ms_1gpu_same_work'] / tn,
                                                                   'pairs_per_s': L / (tn * 1e-3)}
+                    progress(f'{name}: {bname} + gather {gather}: {tn:.2f} ms')
                 except Exception as exc:  # (deterministic failures are the same on every rank)
                     row['variants'][f'{bname}+gather_{gather}'] = {'error': f'{type(exc).__name__}: {str(exc)[:200]}'}
         ok = {k: v for k, v in row['variants'].items() if 'ms' in v}
@@ -512,7 +522,7 @@ def main():
     ap.add_argument('--strong-timeout', type=float, default=420.0, help='N > 1: seconds the strong-scaling figures may take before the line is printed without them')
     ap.add_argument('--no-configs-3-4', action='store_true', help='N > 1: skip `configs_3_4_strong` (the ppa- / citation2-size BUDDY precomputes, strong-scaled)')
     ap.add_argument('--strong-links-cap', type=int, default=int(os.environ.get('SS_BENCH_STRONG_LINKS', '0')) or None,
-                    help='N > 1: cap on the links of a `configs_3_4_strong` precompute (default: the config\'s full link set over RCCL; 4 M with the '
+                    help='N > 1: cap on the links of a `configs_3_4_strong` precompute (default: the config\'s full link set over RCCL; 1 M with the '
                          'gloo test hooks, whose gathers go through the host)')
     ap.add_argument('--no-strong', action='store_true', help='N > 1: skip the strong-scaling figures measured after the timed region')
     ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` shapes measured after the timed region')
@@ -537,6 +547,9 @@ def main():
                '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         sys.exit(subprocess.run(cmd, env=env).returncode)
+    if os.environ.get('SS_BENCH_DUMP_AFTER'):  # debugging aid: every rank prints its Python stack to stderr after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['SS_BENCH_DUMP_AFTER']), exit=False)
     launched = 'RANK' in os.environ  # under torchrun (also with one rank, so the RCCL path can be smoke-tested)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -911,7 +924,7 @@ def main():
     # (every rank runs all of it, no communication) and sharded over the N ranks, for the two jobs BASELINE names: the BUDDY
     # precompute of the config (one build + its link set) and one build + one global batch; with the build replicated and
     # row-sharded (exchange form chosen by dist.choose_exchange's micro-probe).  speedup_vs_n1_same_work = t(1 GPU) / t(N GPUs).
-    if launched and world > 1 and a.api == 'build_query' and not a.no_strong:
+    if launched and world > 1 and a.api == 'build_query':
         # The figures below run collectives that the timed region does not (row exchanges, feature all-gathers).  A rank that
         # fails alone would leave the others waiting in one for ever, and the weak line above is already measured: a watchdog
         # prints it without the figures and ends the process if they take longer than --strong-timeout.
@@ -944,13 +957,16 @@ def main():
             out['build_fastest'] = min(timed_ok, key=timed_ok.get)
         if not a.no_configs_3_4:
             try:
-                cap = a.strong_links_cap or (None if backend == 'nccl' else 4_000_000)
-                out['configs_3_4_strong'] = configs_3_4_strong(ssa, dist, dev, world, rank, with_peer=with_peer, links_cap=cap)
+                # (the gloo test hooks: both ranks time-slice ONE GPU and every gather goes through the host -- a small link set, one repetition)
+                cap = a.strong_links_cap or (None if backend == 'nccl' else 1_000_000)
+                out['configs_3_4_strong'] = configs_3_4_strong(ssa, dist, dev, world, rank, reps=2 if backend == 'nccl' else 1, with_peer=with_peer,
+                                                               links_cap=cap, only=os.environ.get('SS_BENCH_STRONG_ONLY', '').split(',') if os.environ.get('SS_BENCH_STRONG_ONLY') else None)
                 out['configs_3_4_strong']['links_cap'] = cap
             except Exception as exc:
                 out['configs_3_4_strong'] = {'error': f'{type(exc).__name__}: {exc}'}
         try:
-            out['strong'] = strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank, with_peer=with_peer)
+            out['strong'] = ({'skipped': '--no-strong'} if a.no_strong else
+                             strong_scaling_figures(ssa, eh, dist, dev, n, h, ei, cfg, batch, world, rank, with_peer=with_peer))
         except Exception as exc:  # (deterministic failures are the same on every rank; the headline line must survive)
             out['strong'] = {'error': f'{type(exc).__name__}: {exc}'}
         watchdog.cancel()

@@ -412,14 +412,14 @@ class PeerShard(RowShard):
         if entry is None:
             raise RuntimeError('peer-write build unavailable after 3 attempts: ' + ' | '.join(errors))
         self._entry = entry
-        self._slab, self._peer_tensors = entry['slab'], entry['peers']
-        self.mh, self.hll, self.cards = self._carve.views(self._slab)
+        self._slabs, self._peer_tensors = entry['slabs'], entry['peers']
+        self.mh, self.hll, self.cards = self._carve.views(self._slabs)
         self._order = [r for r in range(self.world) if r != self.rank]
         import weakref
         # (the finaliser runs BEFORE the shard's own attributes are cleared: its views of the slab are still alive then, so "no tensor
         # of a build is left" means "the storage has as many users as right now")
         try:
-            users = _storage_users(self._slab)
+            users = _storage_users(self._slabs)
         except Exception as exc:  # noqa: BLE001  (a torch without the private hook: the constructor fails the way fallback=True expects)
             _QUARANTINE.append(entry)
             raise RuntimeError(f'peer-write build unavailable: cannot count the users of a slab ({exc!r})')
@@ -436,7 +436,7 @@ class PeerShard(RowShard):
         # slabs set aside because a caller still held a table of theirs come back once that table is gone
         for q in [q for q in _QUARANTINE if q.get('key') == key and not q.get('bad') and 'idle_users' in q]:
             try:
-                idle = _storage_users(q['slab']) <= q['idle_users']
+                idle = _storage_users(q['slabs']) <= q['idle_users']
             except Exception:  # noqa: BLE001
                 idle = False
             if idle:
@@ -460,17 +460,18 @@ class PeerShard(RowShard):
         return entry
 
     def _new_entry(self, key):
-        slab, mine, failure = None, None, None
+        slabs, mine, failure = [], None, None
         try:
-            slab = torch.empty(self._carve.bytes, dtype=torch.uint8, device=self.device)
-            mine = _export_tables([slab])
+            for nbytes in self._carve.slab_bytes:
+                slabs.append(torch.empty(nbytes, dtype=torch.uint8, device=self.device))
+            mine = _export_tables(slabs)
         except Exception as exc:  # noqa: BLE001
             failure = RuntimeError(f'IPC export failed: {type(exc).__name__}: {str(exc).splitlines()[0]} [{_fd_state()}; {_ipc_probe()}]')
         try:
             self._agree(failure, 'a rank could not export its tables')
         except RuntimeError:
-            if slab is not None:  # on EVERY rank: memory that was (or may have been) exported is never handed back to the allocator
-                _QUARANTINE.append({'slab': slab, 'bad': True})
+            if slabs:  # on EVERY rank: memory that was (or may have been) exported is never handed back to the allocator
+                _QUARANTINE.append({'slabs': slabs, 'bad': True})
             raise
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=self.group)
@@ -479,27 +480,27 @@ class PeerShard(RowShard):
             for r in range(self.world):
                 if r == self.rank:
                     continue
-                (rebuild, args), = everyone[r]
-                peer_slab = rebuild(*args)
-                if peer_slab.device != self.device:  # another GPU of the node: this GPU must be allowed to address its memory
+                peer_slabs = [rebuild(*args) for rebuild, args in everyone[r]]
+                other = peer_slabs[0].device
+                if other != self.device:  # another GPU of the node: this GPU must be allowed to address its memory
                     # asked BEFORE anything touches the mapping: a kernel (or copy) that stores through a mapping its GPU
                     # cannot address faults the whole process (hipDeviceCanAccessPeer)
-                    if not torch.cuda.can_device_access_peer(self.device.index or 0, peer_slab.device.index or 0):
-                        raise RuntimeError(f'{self.device} cannot address the memory of {peer_slab.device} (no peer access)')
-                    _enable_peer_access(self.device, peer_slab.device)
-                pm, ph, pc = self._carve.views(peer_slab)
-                peers[r] = (peer_slab, pm + ph + [pc])
+                    if not torch.cuda.can_device_access_peer(self.device.index or 0, other.index or 0):
+                        raise RuntimeError(f'{self.device} cannot address the memory of {other} (no peer access)')
+                    _enable_peer_access(self.device, other)
+                pm, ph, pc = self._carve.views(peer_slabs)
+                peers[r] = (peer_slabs, pm + ph + [pc])
         except Exception as exc:  # (mapping a peer's memory can fail on ONE rank only: agree before anybody waits for anybody)
             failure = exc
         try:
             self._agree(failure, 'a rank could not map its peers\' tables')
         except RuntimeError:
-            _QUARANTINE.append({'slab': slab, 'peers': peers, 'bad': True})  # (the ranks that did map keep their slab out of the allocator too)
+            _QUARANTINE.append({'slabs': slabs, 'peers': peers, 'bad': True})  # (the ranks that did map keep their slab out of the allocator too)
             raise
         _POOL_IDS[key] = _POOL_IDS.get(key, 0) + 1  # (creations are collective: the counter agrees across ranks)
-        entry = {'id': _POOL_IDS[key], 'slab': slab, 'peers': peers, 'key': key}
+        entry = {'id': _POOL_IDS[key], 'slabs': slabs, 'peers': peers, 'key': key}
         try:
-            entry['idle_users'] = _storage_users(slab)  # (the slab with nobody's views on it: what "no table of a build is left" looks like)
+            entry['idle_users'] = _storage_users(slabs)  # (the slab with nobody's views on it: what "no table of a build is left" looks like)
         except Exception:  # noqa: BLE001
             pass
         return entry
@@ -511,7 +512,7 @@ class PeerShard(RowShard):
         self.hop_barrier()  # (a pooled slab: whatever any rank still has queued on the tables of the shard that held it before completes first)
         entry['probes'] = entry.get('probes', 0) + 1
         token = float(1000 * entry['probes'])  # (a reused slab still holds the tokens of its last probe)
-        _, _, cards = self._carve.views(entry['slab'])
+        _, _, cards = self._carve.views(entry['slabs'])
         failure = None
         try:
             for r, (_, views) in entry['peers'].items():
@@ -576,9 +577,12 @@ _POOL_IDS = {}    # same key -> entries created so far
 _QUARANTINE = []  # slabs / mappings of constructions that failed: never reused, never freed (their memory must not be recycled)
 
 
-def _storage_users(t):
-    """tensors / storage handles that share t's memory right now (the temporary handle of this call included)"""
-    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+def _storage_users(slabs):
+    """tensors / storage handles that share the memory of a slab (or of a list of slabs: the sum) right now, the temporary handle of
+    this call included"""
+    if isinstance(slabs, torch.Tensor):
+        slabs = [slabs]
+    return sum(torch._C._storage_Use_Count(t.untyped_storage()._cdata) for t in slabs)
 
 
 def _release_entry(key, entry, users_of_the_shard_itself):
@@ -586,30 +590,46 @@ def _release_entry(key, entry, users_of_the_shard_itself):
     caller kept a table but not the shard): that slab is then kept aside for good, a later shard must not overwrite the table.
     users_of_the_shard_itself: _storage_users(slab) when the shard stood complete (the slab + the shard's own views)"""
     try:
-        in_use = _storage_users(entry['slab']) > users_of_the_shard_itself
+        in_use = _storage_users(entry.get('slabs') or [entry['slab']]) > users_of_the_shard_itself
     except Exception:  # noqa: BLE001  (interpreter shutdown, a torch without the hook)
         in_use = True
     (_QUARANTINE if in_use else _POOL.setdefault(key, [])).append(entry)
 
 
-class _SlabLayout(object):
-    """where the 2 h + 1 tables of a shard lie inside its one allocation (every table 256-byte aligned)"""
+PEER_SLAB_MAX_BYTES = int(os.environ.get('SS_PEER_SLAB_MAX_MB', '2048')) << 20
 
-    def __init__(self, rows, max_hops, num_perm, m):
+
+class _SlabLayout(object):
+    """where the 2 h + 1 tables of a shard lie inside its allocation(s) (every table 256-byte aligned).  ONE slab while the tables fit
+    PEER_SLAB_MAX_BYTES (2 GiB; ogbl-ppa size: 0.9 GB), otherwise as few slabs of at most that size as a greedy packing in table order
+    gives (a table above the limit gets a slab to itself): opening the IPC handle of a single 6.8 GB slab -- ogbl-citation2 size, h = 3
+    -- never returned (two processes on one MI355X, hipIpcOpenMemHandle under torch's rebuild_cuda_tensor, round 6), five slabs of
+    <= 2 GiB map at once."""
+
+    def __init__(self, rows, max_hops, num_perm, m, max_slab_bytes=None):
         self.rows, self.h, self.P, self.m = rows, max_hops, num_perm, m
         al = lambda x: (x + 255) & ~255
         self.mh_bytes, self.hll_bytes, self.cards_bytes = al(rows * num_perm * 4), al(rows * m), al(rows * max_hops * 4)
-        self.bytes = max_hops * (self.mh_bytes + self.hll_bytes) + self.cards_bytes
+        sizes = [self.mh_bytes] * max_hops + [self.hll_bytes] * max_hops + [self.cards_bytes]
+        limit = PEER_SLAB_MAX_BYTES if max_slab_bytes is None else max_slab_bytes
+        self.place, self.slab_bytes = [], []  # table -> (slab, offset); bytes of every slab
+        for size in sizes:
+            if not self.slab_bytes or (self.slab_bytes[-1] + size > limit and self.slab_bytes[-1] > 0):
+                self.slab_bytes.append(0)
+            self.place.append((len(self.slab_bytes) - 1, self.slab_bytes[-1]))
+            self.slab_bytes[-1] += size
+        self.bytes = sum(self.slab_bytes)
 
-    def views(self, slab):
-        off, mh, hll = 0, [], []
-        for _ in range(self.h):
-            mh.append(slab[off:off + self.rows * self.P * 4].view(torch.int32).view(self.rows, self.P))
-            off += self.mh_bytes
-        for _ in range(self.h):
-            hll.append(slab[off:off + self.rows * self.m].view(self.rows, self.m))
-            off += self.hll_bytes
-        cards = slab[off:off + self.rows * self.h * 4].view(torch.float32).view(self.rows, self.h)
+    def views(self, slabs):
+        """slabs: the list of allocations (a single tensor is accepted while the layout has one slab)"""
+        if isinstance(slabs, torch.Tensor):
+            slabs = [slabs]
+        if len(slabs) != len(self.slab_bytes):
+            raise ValueError(f'this layout has {len(self.slab_bytes)} slab(s), got {len(slabs)}')
+        piece = lambda t, n: slabs[self.place[t][0]][self.place[t][1]:self.place[t][1] + n]
+        mh = [piece(k, self.rows * self.P * 4).view(torch.int32).view(self.rows, self.P) for k in range(self.h)]
+        hll = [piece(self.h + k, self.rows * self.m).view(self.rows, self.m) for k in range(self.h)]
+        cards = piece(2 * self.h, self.rows * self.h * 4).view(torch.float32).view(self.rows, self.h)
         return mh, hll, cards
 
 

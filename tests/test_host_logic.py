@@ -1,5 +1,6 @@
 """Host-side logic of the ElphHashes mirror that needs no GPU: constants, constructor contract, parameter
 derivation, containers, sharding arithmetic -- and that compute entry points refuse to run without a HIP device."""
+import os
 import pickle
 from argparse import Namespace
 
@@ -266,7 +267,8 @@ def test_byte_model_of_the_step(ssa):
     impl = rf.step_bytes_implemented(n, e, 128, 8, 2, 65536)
     assert impl < survey and abs(impl - 2.66e9) < 0.1e9             # hop 1 reads no table, the CSR build at its algorithmic 20E + 8N: ~2.66 GB per step
     assert rf.residency(n, 'minhash_hop') == 'infinity-cache' and rf.residency(2927963, 'minhash_hop') == 'hbm'
-    assert rf.residency(576289, 'minhash_hop') == 'hbm' and rf.residency(576289, 'hll_hop') == 'infinity-cache'
+    assert rf.residency(576289, 'minhash_hop') == 'mixed' and rf.residency(576289, 'hll_hop') == 'infinity-cache'  # (295 MB: 87 % of it fits the cache)
+    assert rf.residency(2927963, 'pair_features', h=3) == 'hbm' and rf.resident_label(300 << 20) == 'mixed'
     assert rf.unique_bytes(n, e, 'minhash_hop') == 2 * n * 512 + 4 * e + 8 * (n + 1)
     assert rf.csr_bytes(n, e) == 20 * e + 8 * (n + 1)               # algorithmic: edge list read once, col + rowptr written once
     ids = 516 / 512  # (the probe's id bytes counted)
@@ -459,6 +461,21 @@ def test_peer_shard_slab_layout_and_pool_release(ssa):
     cards.fill_(0.5)
     mh2, hll2, cards2 = L.views(slab)  # (what a peer carves out of the mapped slab)
     assert all(int(t[7, 5]) == k + 1 for k, t in enumerate(mh2 + hll2)) and float(cards2[1000, 2]) == 0.5
+    # above PEER_SLAB_MAX_BYTES the tables are packed into several slabs in table order (a 6.8 GB slab -- citation2 size -- could not be
+    # opened through IPC): same views, every slab within the limit unless a single table exceeds it
+    assert len(L.slab_bytes) == 1 and L.place[0] == (0, 0)
+    M = D._SlabLayout(1001, 3, 128, 256, max_slab_bytes=700000)
+    assert len(M.slab_bytes) == 5 and M.bytes == L.bytes and all(b <= 700000 for b in M.slab_bytes)
+    parts = [torch.zeros(b, dtype=torch.uint8) for b in M.slab_bytes]
+    mh3, hll3, cards3 = M.views(parts)
+    assert [tuple(t.shape) for t in mh3 + hll3] == [(1001, 128)] * 3 + [(1001, 256)] * 3 and tuple(cards3.shape) == (1001, 3)
+    for k, t in enumerate(mh3 + hll3 + [cards3]):
+        t.fill_(k + 1)
+    assert all(bool((t == k + 1).all()) for k, t in enumerate(mh3 + hll3 + [cards3]))  # no table overlaps another
+    assert len(D._SlabLayout(2927976, 3, 128, 256).slab_bytes) == 5 and max(D._SlabLayout(2927976, 3, 128, 256).slab_bytes) <= 2 << 30
+    with pytest.raises(ValueError):
+        M.views(parts[:2])
+    del mh3, hll3, cards3, parts
     # release: pooled when nothing else refers to the slab's storage, set aside when a view survives the shard
     key = ('test', L.bytes, 'cpu')
     D._POOL.pop(key, None)
@@ -484,3 +501,38 @@ def test_peer_shard_slab_layout_and_pool_release(ssa):
     del kept
     D._POOL.pop(key, None)
     D._QUARANTINE.pop()
+
+
+def test_import_of_external_fixtures_dry_run(ssa, tmp_path):
+    """tools/import_external_fixtures.sh + the exporters are the only way the third-party holes (datasketch's tables,
+    real PyG) ever close -- so the path is exercised: the committed REGENERATED tables are written in the exporter's own format
+    (tools/export_datasketch_fixture.write_tables), the import script validates them in --dry-run (nothing is installed), regenerates
+    the golden vectors from the reference with those tables (where /root/reference exists) and must report that NO array moved --
+    same numbers in, same vectors out; a truncated file must be refused"""
+    import importlib.util
+    import subprocess
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location('export_datasketch_fixture', os.path.join(REPO, 'tools', 'export_datasketch_fixture.py'))
+    exporter = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(exporter)
+    tables = {p: ssa.hll_tables.load(p, prefer='regenerated') for p in range(4, 17)}
+    path = tmp_path / 'hllpp_tables_datasketch.npz'
+    exporter.write_tables(str(path), tables)
+    back = ssa.hll_tables._from_export(8, str(path))  # format round trip: what the engine would load from the installed file
+    assert back.provenance == 'datasketch-export' and ssa.hll_tables.same_tables(ssa.hll_tables.table_id(back), ssa.hll_tables.table_id(tables[8]))
+    installed = [os.path.join(REPO, 'subgraph-sketching_amd', 'data', 'hllpp_tables_datasketch.npz'), os.path.join(REPO, 'tests', 'golden', 'g13_pyg_sign.npz')]
+    before = [os.path.exists(f) for f in installed]
+    done = subprocess.run(['bash', os.path.join(REPO, 'tools', 'import_external_fixtures.sh'), '--dry-run', str(tmp_path)], capture_output=True, text=True,
+                          timeout=900)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert [os.path.exists(f) for f in installed] == before, 'a dry run must not install anything'
+    assert 'dry run: would install' in done.stdout and 'datasketch tables for p in [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]' in done.stdout
+    if os.path.isdir('/root/reference'):
+        assert 'arrays that moved: 0' in done.stdout, done.stdout[-3000:]
+    else:
+        assert 'cannot be regenerated on this machine' in done.stdout
+    # a file that is not the exporter's is refused before anything is touched
+    np.savez(tmp_path / 'hllpp_tables_datasketch.npz', p_list=np.asarray([8]), raw_p8=np.zeros(3))
+    bad = subprocess.run(['bash', os.path.join(REPO, 'tools', 'import_external_fixtures.sh'), '--dry-run', str(tmp_path)], capture_output=True, text=True,
+                         timeout=120)
+    assert bad.returncode != 0 and 'missing' in bad.stderr

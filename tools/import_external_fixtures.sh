@@ -1,5 +1,7 @@
 #!/bin/bash
-# usage: bash tools/import_external_fixtures.sh <dir>
+# usage: bash tools/import_external_fixtures.sh [--dry-run] <dir>
+#   --dry-run: validate and report exactly as below but install NOTHING (tests/test_host_logic.py runs it on a copy of the committed
+#   regenerated tables written in the exporter's format, so that this five-minute path cannot rot unnoticed)
 # <dir> holds what the two exporters wrote on a machine that has the third-party packages this image lacks:
 #   hllpp_tables_datasketch.npz  (+ g11_datasketch_tables.npz)   tools/export_datasketch_fixture.py   (needs datasketch)
 #   g13_pyg_sign.npz                                             tools/export_pyg_fixture.py          (needs torch_geometric + torch_sparse)
@@ -8,14 +10,19 @@
 # changed, on how many entries and by how much (only values on the bias-corrected branch -- the `*_uses_tables` masks -- may move).
 # Nothing is committed: the script ends with the git commands to run after a look at the report.
 set -e
-SRC=${1:?usage: bash tools/import_external_fixtures.sh <dir>}
+DRY=0
+if [ "$1" = "--dry-run" ]; then DRY=1; shift; fi
+SRC=${1:?usage: bash tools/import_external_fixtures.sh [--dry-run] <dir>}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$ROOT"
-python - "$SRC" <<'PY'
+python - "$SRC" "$DRY" <<'PY'
 import os, shutil, subprocess, sys, tempfile
 import numpy as np
-src, root = sys.argv[1], os.getcwd()
+src, root, dry = sys.argv[1], os.getcwd(), sys.argv[2] == '1'
 installed = []
+_copy = shutil.copyfile
+if dry:
+    shutil.copyfile = lambda a, b: print(f'(dry run: would install {os.path.relpath(b, root)})')
 
 def fail(msg):
     sys.exit(f'import_external_fixtures: {msg}')
@@ -72,6 +79,7 @@ if os.path.exists(tables):
         with tempfile.TemporaryDirectory() as tmp:
             env = dict(os.environ, SS_GOLDEN_TABLES=tables, SS_GOLDEN_OUT=tmp)
             subprocess.run([sys.executable, os.path.join('tests', 'golden', 'make_golden.py')], check=True, env=env, stdout=subprocess.DEVNULL)
+            changed_arrays = 0
             print('\ngolden vectors regenerated with datasketch\'s tables vs the committed ones (regenerated tables):')
             for name in sorted(f for f in os.listdir(tmp) if f.endswith('.npz')):
                 new, old = np.load(os.path.join(tmp, name)), np.load(os.path.join('tests', 'golden', name))
@@ -81,7 +89,9 @@ if os.path.exists(tables):
                     a, b = new[key].astype(np.float64), old[key].astype(np.float64)
                     moved = ~np.isclose(a, b, rtol=0, atol=0, equal_nan=True)
                     if moved.any():
+                        changed_arrays += 1
                         print(f'  {name}:{key}: {int(moved.sum())} of {moved.size} entries changed, max |diff| = {np.nanmax(np.abs(a - b)[moved]):.6g}')
+            print(f'arrays that moved: {changed_arrays}')
             print('(arrays not listed are unchanged.  To adopt the real tables as the pinned ones: re-run tests/golden/make_golden.py with\n'
                   ' SS_GOLDEN_TABLES set and commit its output together with the installed files)')
 

@@ -54,7 +54,8 @@ def main():
         hbm = (2 * raw.get('FETCH_SIZE_KB_avg', 0) + raw.get('WRITE_SIZE_KB_avg', 0)) * 1024 if raw else None
         if fam and model[fam] > 0:
             alg = model[fam]
-            res = rf.residency(n, fam) if fam in ('minhash_hop', 'hll_hop') else '-'
+            res = (f'{rf.residency(n, fam, 128, 8, h)} ({rf.cache_resident_fraction(rf.gathered_table_bytes(n, fam, 128, 8, h)):.2f} cached)'
+                   if fam in ('minhash_hop', 'hll_hop', 'fused_first_hop_hll_hop', 'pair_features') else '-')
             # the fraction is taken on the algorithmic bytes CAPPED at the bytes the PMC passes saw crossing the fabric when those are
             # fewer (a row kernel on a skewed graph re-reads source rows out of the L2: repeats are not traffic) -- the rule of
             # bench.py's roofline_numbers, so that no tracked table prints a fraction above 1
