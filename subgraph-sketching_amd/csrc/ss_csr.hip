@@ -689,6 +689,7 @@ struct RowOutputs {
     int32_t *err;         // the build's err_flag (nullable): bit 1 (SS_CSR_ERR_PROTOCOL) reports a wait that gave up, see wait_until
     int32_t *fault_word;  // process-wide count of such waits in pinned host memory (nullable; ss_csr_protocol_faults reads it without synchronising)
     unsigned long long wait_ticks;  // bound of wait_until
+    uint32_t walk_max;    // buckets of up to this many edges are finished by their own workgroup (kDenseMin: only what fits the image; kWalkMax)
 };
 
 // exclusive scan of the per-node edge counts cnt[0..nb) of the bucket that starts at node0 -> excl[0..nb]; with `publish` the
@@ -799,14 +800,21 @@ __device__ __forceinline__ bool wait_until(int32_t *word, int target, int *flag,
 }
 
 // ---- finish over runs ------------------------------------------------------------------------------------------------------------
-constexpr int kRunBlocks = (kDenseMin + kTile) / kWave;  // 64-position blocks of the largest bucket / share a workgroup walks
+// A bucket of up to kWalkMax edges -- above the image, but not by much -- is still finished by its OWN workgroup, image by image (node
+// ranges whose rows fit the image, every pass re-reading the bucket's records): under id-correlated skew most buckets that do not
+// fit the image are of this kind (ogbl-ppa size, rank^-0.5 endpoints: ~135 of ~180), and two or three shares each through the
+// count / place protocol cost them several times what one more sweep costs (round 6).  Only what is larger, or holds a single row
+// above the image, is registered and worked off in shares.
+constexpr int kWalkMax = 3 * kFinishCap;  // (what the tables are sized for; the launch picks 1 .. 3 images, see finish_walk_max)
+constexpr int kRunBlocks = kWalkMax / kWave;  // 64-position blocks of the largest bucket / share a workgroup walks
+static_assert(kWalkMax >= kDenseMin + kTile, "a share (at most kDensePart edges + one run) is walkable");
 struct RunLds {
     uint32_t delta[kRunCap];           // first record of the run of each listed tile MINUS the run's first position: record = delta + position
     uint16_t start[kRunCap + 4];       // exclusive prefix of the run lengths: position of each run's first edge; [n] = total, then 0xFFFF
     uint16_t first_run[kRunBlocks + 2];  // the run that holds the first position of each 64-position block
     uint32_t wave_tot[kDenseThreads / kWave];
 };
-static_assert(kDenseMin + kTile < 65536 && kDensePart <= kDenseMin, "16-bit positions");
+static_assert(kWalkMax < 65536 && kDensePart <= kDenseMin, "16-bit positions");
 
 // The runs (tile, k) of the tiles [t_lo, t_hi) as an edge source for the finish step and the dense steps, walked by POSITION: the edges
 // of the listed runs are numbered 0 .. total in tile order and thread i takes positions i, i + THREADS, ...: every lane has an edge
@@ -1462,7 +1470,7 @@ __global__ __launch_bounds__(kRunThreads) __attribute__((amdgpu_waves_per_eu(4, 
         // dedicated helpers leave when every bucket has decided and nothing is registered
         sc = edges.scan(c.t_lo, c.t_hi - c.t_lo, &base);
         announced = true;
-        if (sc.total <= (uint32_t)kDenseMin) {  // (workgroup-uniform)
+        if (sc.total <= o.walk_max) {  // (workgroup-uniform) finished here: in one image, or image by image
             dense.arrive();
             edges.tables(c.t_hi - c.t_lo, sc);
         }
@@ -1511,20 +1519,44 @@ __global__ __launch_bounds__(kRunThreads) __attribute__((amdgpu_waves_per_eu(4, 
     dense.t_hi = c.t_hi;
     SS_TICK(0);
     const int nb = 1 << node_shift;  // <= 1024 nodes
-    if (n > (uint32_t)kDenseMin) {  // (workgroup-uniform) does not fit the image: registered, then worked off share by share by everybody
+    uint32_t *cnt = lds.cnt;
+    // above the image but walkable (resident descriptors, <= walk_max edges): counted here first -- it stays with this workgroup unless
+    // ONE row alone exceeds the image (then it is registered like the larger ones; nothing has been published yet)
+    bool by_images = false;  // (workgroup-uniform)
+    if (n > (uint32_t)kDenseMin && n <= o.walk_max && resident) {
+        for (int i = threadIdx.x; i < nb; i += kRunThreads) cnt[i] = 0;
+        __syncthreads();
+        edges.for_each([&](int, int y) { atomicAdd(&cnt[y], 1u); });
+        __syncthreads();
+        uint32_t big = 0;
+        for (int i = threadIdx.x; i < nb; i += kRunThreads) big = cnt[i] > big ? cnt[i] : big;
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const uint32_t x = __shfl_xor(big, off);
+            big = x > big ? x : big;
+        }
+        if ((threadIdx.x & (kWave - 1)) == 0) red_n[threadIdx.x / kWave] = big;
+        __syncthreads();
+        big = 0;
+        for (int w = 0; w < kRunThreads / kWave; ++w) big = red_n[w] > big ? red_n[w] : big;
+        by_images = big <= (uint32_t)kFinishCap;
+        __syncthreads();
+    }
+    if (n > (uint32_t)kDenseMin && !by_images) {  // (workgroup-uniform) registered, then worked off share by share by everybody
         own = announced ? dense.register_from_prefix(lds, base, n, nb, sc.ex, sc.len) : dense.register_bucket(lds, base, n, nb);
         SS_MARK(14);
     } else {
     if (!announced) dense.arrive();
     SS_MARK(15);
-    uint32_t *cnt = lds.cnt;
+    if (!by_images) {
     for (int i = threadIdx.x; i < nb; i += kRunThreads) cnt[i] = 0;
     __syncthreads();
+    }
     // (workgroup-uniform) packed records: the counting sweep leaves them in the image array and the placing sweep takes them from
     // there -- no second gather, no second run lookup (ppa-size finish: 9.3 us of 26.7 per workgroup)
-    const bool stashed = PACKED && edges.resident();
+    const bool stashed = PACKED && edges.resident() && !by_images;
     uint32_t *stash = reinterpret_cast<uint32_t *>(lds.image);
-    if (stashed) edges.for_each_stash(stash, [&](int, int y) { atomicAdd(&cnt[y], 1u); });
+    if (by_images) {}  // (counted above)
+    else if (stashed) edges.for_each_stash(stash, [&](int, int y) { atomicAdd(&cnt[y], 1u); });
     else edges.for_each([&](int, int y) { atomicAdd(&cnt[y], 1u); });
     __syncthreads();
     SS_TICK(1);
@@ -1537,6 +1569,36 @@ __global__ __launch_bounds__(kRunThreads) __attribute__((amdgpu_waves_per_eu(4, 
     // sweep); a bucket registered later than this look is worked off by its own workgroup and by whoever finishes later
     const int registered = __hip_atomic_load(&dense.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
                            __hip_atomic_load(&dense.count[kSpentWord], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (registered, not yet given away)
+    if (by_images) {
+        // node ranges [lo, hi) whose rows together fit the image, one after the other: every pass walks the bucket's records again
+        // (they were read a moment ago: L2) and keeps the edges of its nodes -- two passes for a bucket of up to two images, a
+        // third when the cut falls badly
+        for (int lo = 0; lo < nb;) {  // (workgroup-uniform)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t lim = lds.excl[lo] + (uint32_t)kFinishCap;  // (every row fits: checked above, so hi > lo)
+                int a = lo + 1, b = nb;
+                while (a < b) {
+                    const int mid = (a + b + 1) >> 1;
+                    if (lds.excl[mid] <= lim) a = mid; else b = mid - 1;
+                }
+                red_n[1] = (uint32_t)a;
+            }
+            __syncthreads();
+            const int hi = (int)red_n[1];
+            const uint32_t e0 = lds.excl[lo], e1 = lds.excl[hi];
+            for (int i = lo + (int)threadIdx.x; i < hi; i += kRunThreads) cnt[i] = lds.excl[i] - e0;  // cursors inside the image
+            __syncthreads();
+            edges.for_each([&](int x, int y) {
+                if (y >= lo && y < hi) lds.image[atomicAdd(&cnt[y], 1u)] = x;
+            });
+            __syncthreads();
+            for (uint32_t q = threadIdx.x; q < e1 - e0; q += kRunThreads) col[base + e0 + q] = lds.image[q];
+            lo = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) red_n[0] = (uint32_t)registered;
+    } else {
     auto place = [&](int x, int y) { lds.image[atomicAdd(&cnt[y], 1u)] = x; };
     if (stashed) edges.replay(stash, n, place);
     else edges.for_each(place);
@@ -1544,6 +1606,7 @@ __global__ __launch_bounds__(kRunThreads) __attribute__((amdgpu_waves_per_eu(4, 
     SS_TICK(3);
     if (threadIdx.x == 0) red_n[0] = (uint32_t)registered;  // (one thread's look decides for the workgroup)
     for (uint32_t q = threadIdx.x; q < n; q += kRunThreads) col[base + q] = lds.image[q];
+    }
     SS_TICK(4);
     SS_MARK(9);
     __syncthreads();  // the image is free (it becomes the helper's LDS), the look is visible
@@ -1812,6 +1875,19 @@ static int32_t *protocol_fault_word()
     }();
     return word;
 }
+// How many images' worth of edges a bucket may hold and still be finished by its own workgroup (image by image).  More than one only
+// when the launch has several workgroups per slot (512 resident: two per CU) -- a one-level plan (ogbl-collab size: 231 buckets)
+// is ONE wave of workgroups, a bucket that sweeps twice is the launch's critical path while other CUs idle, and the share protocol,
+// which spreads a bucket over those CUs, wins (measured: 58.8 -> 69.6 us at rank^-0.5); with thousands of buckets the sweeps of one
+// overlap the others' (ogbl-ppa size, rank^-0.5: 602.5 / 495.0 / 491.6 us with 1 / 2 / 3 images, ogbl-citation2 size 959.8 / 735.2 / 726.6;
+// rank^-0.9: 716 / 684 / 643 and 1 106 / 982 / 955; profiles/round6_csr_walk_images.txt).  SS_CSR_WALK_IMAGES = 1 .. 3 forces a
+// value (1: every bucket above the image goes through the share protocol, as in round 5).
+static uint32_t finish_walk_max(int64_t fine_buckets)
+{
+    static const int env = getenv("SS_CSR_WALK_IMAGES") ? atoi(getenv("SS_CSR_WALK_IMAGES")) : 0;
+    const int images = (env >= 1 && env <= 3) ? env : (fine_buckets > 2048 ? 3 : 1);
+    return (uint32_t)(images * ss::kFinishCap);
+}
 // SS_CSR_WAIT_TICKS (100 MHz ticks; test hook: 0 makes every wait that is not already satisfied give up): the bound of wait_until
 static unsigned long long protocol_wait_ticks()
 {
@@ -1842,7 +1918,7 @@ static int csr_build_launch(const ss::LevelPlan &lp, const int64_t *src, const i
         return SS_OK;
     }
     ProfileSpan span(stream, SS_PROF_CSR);  // all launches of this build
-    const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count, skip, err_flag, protocol_fault_word(), protocol_wait_ticks()};
+    const RowOutputs rows_out = {rowptr, (int)hub_threshold, hub_rows, hub_count, mega_rows, mega_count, skip, err_flag, protocol_fault_word(), protocol_wait_ticks(), finish_walk_max(lp.groups[lp.levels])};
     const Workspace w = carve(lp, E, workspace);
     unsigned long long *n_self = n_self_loops_out ? reinterpret_cast<unsigned long long *>(n_self_loops_out) : w.scratch;
     const int tiles0 = (int)lp.tmax[0];

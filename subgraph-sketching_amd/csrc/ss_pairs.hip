@@ -527,9 +527,18 @@ int launch_pairs(const int64_t *links, int64_t B, int64_t N, const PairTables &t
     int64_t blocks = (B + per_group * pairs_per_block - 1) / (per_group * pairs_per_block);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
+    // Which register budget (TP = 128 only: one more instantiation per hop count).  Walks with locality: the capped build (OCC, see the
+    // kernel).  As-listed random pairs, round 6 (tools/probe_pairs_variants.py, profiles/round6_pairs_variants.txt; tables of 0.2 - 6.4
+    // GB, cold and after 2 000 launches): at H = 3 the fourth wavefront per SIMD wins at every table size while the launch is small --
+    // B = 65 536: -4 .. -9 %, B = 261 424 (ogbl-citation2's batch): -1 .. -5 % -- and is level (+-0.6 %) at 4 M pairs; at H = 2 the fifth
+    // wins 1 - 4 % at B = 65 536 (the bench step's query, ELPH batches) and LOSES 2 - 9 % at 261 424 on tables above ~1.5 GB.
+    // SS_PAIR_OCC = 0 / 1 forces a build (probes).
+    static const int occ_env = getenv("SS_PAIR_OCC") ? atoi(getenv("SS_PAIR_OCC")) : -1;
+    const bool small_launch = H == 3 ? B <= ((int64_t)1 << 21) : B <= 65536;
+    const bool occ = occ_env >= 0 ? occ_env != 0 : (grouped || small_launch);
     {
         ProfileSpan span(stream, SS_PROF_PAIRS, true);
-        if (grouped && TP == 128 && H >= 2)  // (the default sketch shape only: one more instantiation per hop count)
+        if (occ && TP == 128 && H >= 2)
             span.launch(pair_features_kernel<H, TP, TM, (TP == 128 && H >= 2)>, dim3((unsigned)blocks), dim3(256), links, B, N, tabs, P, M, cards,
                         cards_stride, prm, flags, out, dbg_match, dbg_zero, dbg_inter, err, degrees, order);
         else

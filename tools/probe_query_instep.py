@@ -88,6 +88,43 @@ def step():
     eh.get_subgraph_features(links, t, c)
 span('query inside the bench step (build + query)', step, reps=10)
 
+
+
+def step_then(gap_cycles=0, sync=False, twice=False):
+    def body():
+        t, c = eh.build_hash_tables(n, ei)
+        if sync:
+            torch.cuda.synchronize()
+        if gap_cycles:
+            torch.cuda._sleep(gap_cycles)
+        eh.get_subgraph_features(links, t, c)
+        if twice:
+            lib.ss_profile_enable(0)  # (only the SECOND query of the step is timed)
+            lib.ss_profile_enable(1 << nat.PROF_PAIRS)
+    return body
+
+
+def second_query():
+    t, c = eh.build_hash_tables(n, ei)
+    lib.ss_profile_enable(0)
+    eh.get_subgraph_features(links, t, c)      # untimed: warms whatever the build left cold
+    lib.ss_profile_enable(1 << nat.PROF_PAIRS)
+    eh.get_subgraph_features(links, t, c)
+    lib.ss_profile_enable(0)
+    lib.ss_profile_enable(1 << nat.PROF_PAIRS)
+span('step: build, host synchronise, query', step_then(sync=True), reps=10)
+span('step: build, ~1 ms idle stream, query', step_then(gap_cycles=2000000), reps=10)
+span('step: build, query (untimed), query (timed)', second_query, reps=10)
+fixed_t, fixed_c = eh.build_hash_tables(n, ei)
+
+
+def other_traffic():
+    # 19 ms of somebody else's traffic over OTHER memory (a build whose tables are thrown away), then the query on tables that have
+    # not been written since: separates "the tables were just written" from "the GPU was just busy elsewhere"
+    eh.build_hash_tables(n, ei)
+    eh.get_subgraph_features(links, fixed_t, fixed_c)
+span('another build (other memory), then query on OLD tables', other_traffic, reps=10)
+
 # synthetic tables as tools/probe_pairs.py makes them
 g = torch.Generator(device=dev).manual_seed(1)
 smh = [torch.randint(-2**31, 2**31 - 1, (n, 128), dtype=torch.int32, device=dev, generator=g) for _ in range(h)]
