@@ -46,7 +46,8 @@ constexpr int kMaxLevels = 3;
 constexpr int kSortThreads = 512;      // level 0: 8 edges per thread (256 threads x 16 edges: 19.3 us on the collab-like graph, 512 x 8: 16.1 us)
 constexpr int kRegroupThreads = 512;   // levels >= 1
 constexpr int kRegroupRuns = 512;      // run descriptors a regroup workgroup holds at a time (more: further rounds)
-constexpr int kRunThreads = 512;       // finish: two workgroups per CU at 128 VGPRs, positions in steps of 512 (less padding than 1024)
+constexpr int kRunThreads = 512;       // finish: two workgroups per CU at 128 VGPRs, positions in steps of 512 (less padding than 1024; round 6: 1 024 threads
+                                       // for one-level plans -- one workgroup per CU there -- measured 38 -> 44 us at ogbl-collab size, 72 -> 81 at rank^-0.9: not shipped)
 constexpr int kDenseThreads = 1024;    // upper bound of the workgroup size of anything that walks shares (LDS arrays are sized for it)
 constexpr int kFinishCap = 16384;      // edges of a bucket's col image in LDS (64 KiB)
 constexpr int kRunCap = 1024;          // run descriptors the finish step keeps in LDS (two workgroups per CU: 80 KB each)

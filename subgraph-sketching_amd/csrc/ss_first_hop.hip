@@ -146,7 +146,7 @@ constexpr int kHllRows = 4;  // (2, 6 and 8 measured the same 25 us on the bench
 template <int PPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void hll_first_hop_kernel(
     GraphArgs g, int p, uint8_t *__restrict__ hll_out, float *__restrict__ cards_out, int64_t cards_stride, ss_hll_params prm, bool skip_hubs,
-    int hub_blocks, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb, uint32_t *__restrict__ hub_mh_out)
+    int hub_blocks, const uint64_t *__restrict__ pa, const uint64_t *__restrict__ pb, uint32_t *__restrict__ hub_mh_out, bool interleave)
 {
     // only the linear-counting table is staged (this kernel is only launched for p = 8: 257 entries): a hop-1 row leaves the
     // linear-counting range at 147 neighbours, and those few read raw / bias from global memory.  17 KB of LDS and 60 VGPRs
@@ -177,7 +177,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void h
     // kHllRows rows per lane group, one after the other through the same LDS row image; the row bounds and the first
     // neighbour ids of ALL of them are requested up front, so the two dependent global round trips (rowptr -> col) of
     // the later rows hide under the work of the earlier ones
-    const int64_t first = g.row0 + ((int64_t)((int)blockIdx.x - hub_blocks) * (blockDim.x / kRow) + grp) * kHllRows;
+    // Row r of lane group `grp` is row r * 16 + grp of the workgroup's 64: at any moment the 16 lane groups work on 16 CONSECUTIVE rows
+    // -- consecutive stretches of `col` and of the output (round 6; SS_HLL_ROW_MAP=0: the four consecutive rows per lane group of
+    // rounds 2-5, whose shared boundary lines were fetched twice at ogbl-ppa size)
+    const int groups = (int)(blockDim.x / kRow);
+    const int64_t wg_first = g.row0 + (int64_t)((int)blockIdx.x - hub_blocks) * groups * kHllRows;
+    const int64_t first = interleave ? wg_first + grp : wg_first + (int64_t)grp * kHllRows;
+    const int64_t row_step = interleave ? groups : 1;
     const int64_t n_self = g.n_self_dev ? *g.n_self_dev : g.n_self;
     uint32_t *row = rows[grp];
     int64_t rbs[kHllRows];
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void h
     bool oks[kHllRows];
 #pragma unroll
     for (int r = 0; r < kHllRows; ++r) {
-        oks[r] = first + r < g.row1;
-        const int64_t i = oks[r] ? first + r : g.row1 - 1;
+        oks[r] = first + r * row_step < g.row1;
+        const int64_t i = oks[r] ? first + r * row_step : g.row1 - 1;
         rbs[r] = g.rowptr[i];
         degs[r] = (int)(g.rowptr[i + 1] - rbs[r]);
     }
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void h
     for (int r = 0; r < kHllRows; ++r) {
         if (r + 2 < kHllRows) nid0[r + 2] = *(l < degs[r + 2] ? g.col + rbs[r + 2] + l : always_valid);
         const bool ok = oks[r];
-        const int64_t i = ok ? first + r : g.row1 - 1;
+        const int64_t i = ok ? first + r * row_step : g.row1 - 1;
         const int deg = degs[r];
         const bool hub = skip_hubs && deg > g.hub_threshold;
         const int total = hub ? 0 : deg + (i < n_self ? 1 : 0);
@@ -348,9 +354,10 @@ template <int PPL>
 static int launch_hll_rows(const GraphArgs &g, int p, uint8_t *hll_out, float *cards_out, int64_t cards_stride, const ss_hll_params &prm,
                            bool skip_hubs, int lead, const uint64_t *a, const uint64_t *b, uint32_t *hub_mh_out, hipStream_t s)
 {
+    static const bool interleave = !(getenv("SS_HLL_ROW_MAP") && atoi(getenv("SS_HLL_ROW_MAP")) == 0);  // (measurement hook, see the kernel)
     ProfileSpan span(s, SS_PROF_FIRST_HOP_HLL);
     hipLaunchKernelGGL((hll_first_hop_kernel<PPL>), dim3((unsigned)((g.rows() + 16 * kHllRows - 1) / (16 * kHllRows) + lead)), dim3(256), 0, s, g,
-                       p, hll_out, cards_out, cards_stride, prm, skip_hubs, lead, a, b, hub_mh_out);
+                       p, hll_out, cards_out, cards_stride, prm, skip_hubs, lead, a, b, hub_mh_out, interleave);
     SS_LAUNCH_CHECK();
     return SS_OK;
 }
