@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsubgraph_sketch.so')
+# (SS_LIB: measurement hook -- tools/ablate_fused.sh loads deliberately incomplete builds of the library to time what is left)
+LIB_PATH = os.environ.get('SS_LIB') or os.path.join(_HERE, 'libsubgraph_sketch.so')
 
 SS_MAX_HOPS = 3
 SS_MAX_TABLE = 512

@@ -176,12 +176,22 @@ __device__ __forceinline__ void fused_hop_body(const GraphArgs &g, const uint64_
         const bool hub = skip_hubs && h.deg > g.hub_threshold;
         h.write = ok && !hub;
         h.total = h.write ? h.deg + (h.i < m.n_self ? 1 : 0) : 0;
+        if constexpr (!(SS_FUSED_ABLATE & 2)) {
         hll_post<0>(h, hll_in, ids_cur.my_nb, c);              // HLL rows of chunk k
         hll_post_lds<kHllInFlight>(h, hll_in, ids_cur.my_nb, c, lds_wave);
+        }
         const Ids ids_next = load_ids(chunk + stride, rp_next); // ids of chunk k + 1 (its bounds arrived during the last walk)
         const int64_t rp_after = load_bounds(chunk + 2 * stride);  // bounds of chunk k + 2
+        if constexpr (!(SS_FUSED_ABLATE & 1)) {
 #pragma unroll 1
         for (int r = 0; r < m.rows; ++r) m.row(r, mh_out);       // MinHash first hop of chunk k: VALU work under all of the above
+        }
+        if constexpr (SS_FUSED_ABLATE & 2) {
+            rp_cur = rp_next;
+            rp_next = rp_after;
+            ids_cur = ids_next;
+            continue;
+        }
         u32x4 ae = {0u, 0u, 0u, 0u}, ao = {0u, 0u, 0u, 0u};
         hll_fold(h, ae, ao);
         if constexpr (kHllLds > 0) {

@@ -2,6 +2,14 @@
 #pragma once
 #include "ss_common.hpp"
 
+// Measurement build only (SS_EXTRA_FLAGS=-DSS_FUSED_ABLATE=<mask>, tools/ablate_fused.sh): parts of the fused stage's wavefront are left out so
+// that what each costs can be read off the launch's duration -- the results of such a build are WRONG by construction.
+//   1: no MinHash rows at all   2: no HLL side (post / fold / finish)   4: no exact evaluation of the winners (phase 2 + ambiguity)
+//   8: no two-phase walk (the update loop)   16: neighbour ids are not hashed   32: no winner fetch (the two ds_bpermute per permutation and segment)
+#ifndef SS_FUSED_ABLATE
+#define SS_FUSED_ABLATE 0
+#endif
+
 namespace ss {
 
 __device__ __forceinline__ u32x4 shfl_xor4(u32x4 v, int mask)
@@ -426,7 +434,7 @@ struct MinhashRows {
     __device__ __forceinline__ void set_batch(int64_t id)
     {
         nid = id;
-        const uint64_t hv = hash_u64((uint64_t)(nid + 1));
+        const uint64_t hv = (SS_FUSED_ABLATE & 16) ? (uint64_t)(nid + 1) : hash_u64((uint64_t)(nid + 1));
         hv_lo = (uint32_t)hv;
         hv_hi = (uint32_t)(hv >> 32);
     }
@@ -489,6 +497,7 @@ struct MinhashRows {
                 // a row that lists itself would meet its implicit self loop as a duplicate (ambiguous for every permutation)
                 seen_self |= __any(lane >= s_lo && lane < s_hi && nid == i);
                 int k = s_lo;
+                if constexpr (!(SS_FUSED_ABLATE & 8)) {
                 for (; k + 3 < s_hi; k += 4) {
                     uint32_t hl[4];
 #pragma unroll
@@ -497,6 +506,7 @@ struct MinhashRows {
                     for (int u = 0; u < 4; ++u) update(hl[u], (uint32_t)(k + u));
                 }
                 for (; k < s_hi; ++k) update((uint32_t)__builtin_amdgcn_readlane((int)hv_lo, k), (uint32_t)k);
+                } else if (s_hi > s_lo) update((uint32_t)__builtin_amdgcn_readlane((int)hv_lo, s_lo), (uint32_t)s_lo);
                 pos = base + (s_hi > s_lo ? s_hi : s_lo);
                 const bool last = pos >= p1;
                 if (last && self && !seen_self) update((uint32_t)__builtin_amdgcn_readlane((int)hv_lo, kNb + r), (uint32_t)(kNb + r));
@@ -504,7 +514,8 @@ struct MinhashRows {
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
                     const int slot = (int)(m1[q] & 63u);
-                    const uint32_t cand_lo = (uint32_t)__shfl((int)hv_lo, slot), cand_hi = (uint32_t)__shfl((int)hv_hi, slot);
+                    const uint32_t cand_lo = (SS_FUSED_ABLATE & 32) ? hv_lo : (uint32_t)__shfl((int)hv_lo, slot);
+                    const uint32_t cand_hi = (SS_FUSED_ABLATE & 32) ? hv_hi : (uint32_t)__shfl((int)hv_hi, slot);
                     const bool changed = m1[q] != before[q];
                     h1_lo[q] = changed ? cand_lo : h1_lo[q];
                     h1_hi[q] = changed ? cand_hi : h1_hi[q];
@@ -512,6 +523,10 @@ struct MinhashRows {
                 if (last) break;
             }
             bool ambiguous = false;
+            if constexpr (SS_FUSED_ABLATE & 4) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) acc[q] = m1[q] ^ h1_lo[q] ^ h1_hi[q] ^ m2[q];
+            } else
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
                 // x = a * h + b (mod 2^64); the permuted hash is x mod (2^61 - 1) = (x & M) + (x >> 61) [- M], whose low word
