@@ -151,7 +151,8 @@ def _sharded_rows(fill, links, width, device, group, gather, block, dtype=torch.
         else:  # 'rank0'
             if native or not on_device:
                 dests = [piece[q * per:(q + 1) * per] for q in range(world)] if rank == 0 else None
-                w = dist.gather(block_view if native else block_view.clone(), dests, dst=root, group=group, async_op=native)
+                # (the root's own block is also dests[0]: it sends from a copy, so that no backend is handed one buffer as input AND output)
+                w = dist.gather(block_view if (native and rank != 0) else block_view.clone(), dests, dst=root, group=group, async_op=native)
                 if native:
                     works.append(w)
             else:
