@@ -737,9 +737,16 @@ static int pair_features_grouped_impl(int which /* -1: chosen per hop count, 0: 
     // L2 -- is ahead or level at every hop count (ppa-size tables, h = 2, random links grouped: 2.69 against 2.63 G pairs/s;
     // citation2-size, h = 3: 1.63 against 1.51); WITHOUT one (runs as listed: a coalesced edge list, an evaluation set) the
     // run-aware kernel wins at h <= 2 (3.49 against 3.24 G pairs/s) and loses at h = 3, where its registers leave two wavefronts
-    // per SIMD (1.73 against 1.93).  SS_PAIR_GROUPED_KERNEL = runs | plain forces one.
+    // per SIMD (1.73 against 1.93).  Round 6 (same probe, profiles/round6_pair_runs.txt): since the ordinary kernel runs the walks with
+    // locality under its capped register budget (five / four wavefronts per SIMD) it also wins the lists walked AS LISTED at h = 2 --
+    // collab-size tables 3.81 against 3.58 G pairs/s (sorted by source) and 4.05 against 3.89 (1 000 negatives per source), ppa size
+    // 3.66 / 3.73 against 3.40 / 3.59, citation2 size 2.59 / 3.16 against 2.32 / 3.02 -- and at h = 3 (2.04-2.08 against 1.34); the
+    // run-aware kernel keeps h = 1 (6.84 against 6.57 on evaluation lists).  A run-aware kernel with u's rows in LDS instead of registers
+    // (global_load_lds landings, ds_read_b128 per comparison) was built and measured: 128 VGPRs + 124 bytes of scratch at four
+    // wavefronts per SIMD (1.34 G pairs/s at h = 3), 170 VGPRs at three (1.93): level with the ordinary kernel's default budget, behind
+    // its capped one -- not shipped.  SS_PAIR_GROUPED_KERNEL = runs | plain forces one.
     static const char *forced = getenv("SS_PAIR_GROUPED_KERNEL");
-    const bool runs = fast && (which >= 0 ? which == 1 : (forced ? !strcmp(forced, "runs") : (order == nullptr && h <= 2)));
+    const bool runs = fast && (which >= 0 ? which == 1 : (forced ? !strcmp(forced, "runs") : (order == nullptr && h <= 1)));
     if (!runs) {
         if (order && B >= ((int64_t)1 << 31)) return SS_ERR_INVALID_ARG;
         return pair_features_impl(links, B, N, h, mh, P, hll, cards, cards_stride, prm, flags, degrees, out, nullptr, nullptr, nullptr,
