@@ -578,6 +578,19 @@ _POOL_IDS = {}    # same key -> entries created so far
 _QUARANTINE = []  # slabs / mappings of constructions that failed: never reused, never freed (their memory must not be recycled)
 
 
+def pool_stats():
+    """{'pooled_bytes', 'pooled_slabs', 'set_aside_bytes', 'set_aside_slabs'} of this process: PeerShard slabs are never handed back to
+    torch's allocator (recycled allocations are what broke IPC exports in rounds 3-4) -- a dropped shard's slabs wait in the
+    pool for the next shard of the same layout, slabs whose tables a caller still holds (or whose construction failed) are set aside
+    until those tables are gone.  A process that builds through many different layouts keeps all of them: this is the number to watch."""
+    def total(entries):
+        slabs = [t for e in entries for t in (e.get('slabs') or ([e['slab']] if 'slab' in e else []))]
+        return sum(t.numel() * t.element_size() for t in slabs), len(slabs)
+    pooled = total([e for free in _POOL.values() for e in free])
+    aside = total(_QUARANTINE)
+    return {'pooled_bytes': pooled[0], 'pooled_slabs': pooled[1], 'set_aside_bytes': aside[0], 'set_aside_slabs': aside[1]}
+
+
 def _storage_users(slabs):
     """tensors / storage handles that share the memory of a slab (or of a list of slabs: the sum) right now, the temporary handle of
     this call included"""

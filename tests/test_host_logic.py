@@ -498,6 +498,8 @@ def test_peer_shard_slab_layout_and_pool_release(ssa):
     kept = shard.cards[:10]  # the caller kept a piece of `cards` of a build through the shard it dropped
     del shard
     assert len(D._POOL[key]) == 1 and len(D._QUARANTINE) == before + 1
+    stats = D.pool_stats()  # what a long-lived process watches: the pool never hands memory back to the allocator
+    assert stats['pooled_slabs'] >= 1 and stats['pooled_bytes'] >= L.bytes and stats['set_aside_slabs'] >= 1 and stats['set_aside_bytes'] >= L.bytes
     del kept
     D._POOL.pop(key, None)
     D._QUARANTINE.pop()
