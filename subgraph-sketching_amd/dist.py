@@ -139,29 +139,30 @@ def _sharded_rows(fill, links, width, device, group, gather, block, dtype=torch.
         piece = full[base:base + world * per] if holds_all else None
         # the round's exchange, issued at once: over RCCL it runs on RCCL's stream behind THIS round's launches (the collective
         # waits for what the current stream holds at this point) and under the next rounds' -- the host does not block
+        # (host tensors on gloo take the SAME deferred form -- issued now, awaited after the last round -- so that the CPU tests walk the
+        # control flow RCCL runs; only device tensors on a backend without device collectives are staged through the host, synchronously)
+        deferred = native or not on_device
         if gather == 'all':
-            if native or not on_device:
-                w = dist.all_gather_into_tensor(piece, block_view if native else block_view.clone(), group=group, async_op=native)
-                if native:
-                    works.append(w)
-            else:  # device tensors on a backend without device collectives (gloo in the one-GPU tests): through the host
+            if deferred:
+                src = block_view if native else block_view.clone()  # (RCCL gathers in place: the input IS the owned block of the output)
+                works.append((dist.all_gather_into_tensor(piece, src, group=group, async_op=True), src))
+            else:
                 staged = torch.empty(piece.shape, dtype=dtype, device='cpu')
                 dist.all_gather_into_tensor(staged, block_view.cpu(), group=group)
                 piece.copy_(staged)
         else:  # 'rank0'
-            if native or not on_device:
+            if deferred:
                 dests = [piece[q * per:(q + 1) * per] for q in range(world)] if rank == 0 else None
                 # (the root's own block is also dests[0]: it sends from a copy, so that no backend is handed one buffer as input AND output)
-                w = dist.gather(block_view if (native and rank != 0) else block_view.clone(), dests, dst=root, group=group, async_op=native)
-                if native:
-                    works.append(w)
+                src = block_view if (native and rank != 0) else block_view.clone()
+                works.append((dist.gather(src, dests, dst=root, group=group, async_op=True), src))
             else:
                 dests = [torch.empty((per, width), dtype=dtype, device='cpu') for _ in range(world)] if rank == 0 else None
                 dist.gather(block_view.cpu(), dests, dst=root, group=group)
                 if rank == 0:
                     piece.copy_(torch.cat(dests, dim=0))
-    for w in works:
-        w.wait()  # the current stream waits for the collectives; the host does not block
+    for w, _keep_alive in works:
+        w.wait()  # RCCL: the current stream waits for the collectives, the host does not block
     rows = full[:L] if holds_all else None
     local = None if holds_all else own[:plan.owned_count()]
     return ShardedFeatures(rows, local, lambda: plan.owned_index(device))
