@@ -138,7 +138,11 @@ __global__ __launch_bounds__(256) void first_hop_rows_kernel(GraphArgs g, const 
 // HLL-only first hop, latency-optimised: one 16-lane DPP row per destination (4 destinations in flight per wave).
 // Used when the caller asks for the HLL sketch alone (the two-stream build runs the HLL chain beside the MinHash
 // chain); the one-row-per-wave kernel above is a single dependent chain per wave and takes 4x longer for this.
-constexpr int kHllRows = 4;  // (2, 6 and 8 measured the same 25 us on the bench graph: the kernel is not bound by its prefetch depth)
+#ifndef SS_HLL_ROWS
+#define SS_HLL_ROWS 4
+#endif
+constexpr int kHllRows = SS_HLL_ROWS;  // (2, 6 and 8 measured the same 25 us on the bench graph: the kernel is not bound by its prefetch depth;
+                                       // round 6, -DSS_HLL_ROWS=3 / 4 / 6 / 8: 25.5 / 25.7 / 25.4 / 37.9 us -- 8 spills 100 bytes at the 64-VGPR budget)
 
 // PPL only matters to the leading workgroups (hub units, ss_hub.hpp): with hub_mh_out they also serve the hop-1 MinHash table
 // (P = 64 * PPL) -- ss_fused_hop_stage's row kernel has no register to spare for them.  The register allocator is held to the 64
